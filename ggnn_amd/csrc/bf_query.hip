@@ -1,0 +1,184 @@
+// bf_query: exhaustive scan, the exact ground-truth path.
+// Reference: BruteForceQueryKernel::operator(), src/ggnn/query/bf_query_layer.cu:39-65 (one
+// block per query, N sequential block-reductions) and KBestList (k_best_list.cuh:29-142).
+//
+// This kernel keeps the reference's arithmetic (direct difference form, Q2 tie rule: equal
+// distances keep the lower base index first) but restructures the scan for wave64: one wave
+// per (query, base slice), 64/LPR base rows per coalesced 16 B/lane load instruction, K-best
+// list in registers.  Slices are merged by a second tiny kernel.  (An MFMA Q x B^T tile path
+// for large query batches is planned on top of this parity anchor, see DESIGN.md.)
+#include "traversal.hpp"
+
+namespace ggnn_amd {
+
+struct BfArgs {
+  const void* base;
+  const void* query;
+  int32_t* ids;    // [Nq x slices x K] partial results (or final when slices == 1)
+  float* dists;
+  uint32_t D, Nq, N_base, K, slices, rows_per_slice;
+};
+
+template <typename BaseT, int LPR, int NCH, int R, int MODE>
+__global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
+{
+  constexpr int ROWS = kWave / LPR;
+  constexpr int STEPS = StepsOf<LPR, NCH>::value;
+  using DE = DistEngine<BaseT, LPR, NCH>;
+  using Chunk = typename DE::Chunk;
+  __shared__ float s_d[ROWS * STEPS];
+
+  const int lane = threadIdx.x;
+  const uint32_t n = blockIdx.x / a.slices;
+  const uint32_t slice = blockIdx.x % a.slices;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const BaseT* query = static_cast<const BaseT*>(a.query);
+
+  DE de;
+  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+  const int grp = lane / LPR;
+
+  SortedList<R> best;  // only key/dist/BEST are used
+  best.BEST = a.K;
+  best.SORTED = a.K;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    best.key[r] = kEmptyKey;
+    best.dist[r] = inf_f();
+  }
+
+  const uint32_t begin = slice * a.rows_per_slice;
+  const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
+  for (uint32_t i0 = begin; i0 < end; i0 += ROWS * STEPS) {
+    Chunk v[STEPS][NCH];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const uint32_t row = i0 + s * ROWS + grp;
+      const bool valid = row < end;
+      const BaseT* rp = de.row_ptr(valid ? row : begin);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        v[s][c] = ChunkOf<BaseT>::zero();
+        if (valid && de.chunk_valid(c))
+          v[s][c] = de.load_chunk(rp, c);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      float x, y;
+      de.template partial<MODE>(v[s], x, y);
+      x = group_sum<LPR>(x);
+      if (MODE == kCos)
+        y = group_sum<LPR>(y);
+      if (de.g == 0)
+        s_d[s * ROWS + grp] = (MODE == kCos) ? de.finish_cos(x, y) : x;
+    }
+    __syncthreads();
+    // visit the batch in base order (bf_query_layer.cu:52-57)
+    const uint32_t cnt = min((uint32_t)(ROWS * STEPS), end - i0);
+    const float cd = lane < (int)cnt ? s_d[lane] : inf_f();
+    unsigned long long m = __ballot(cd < best.dist_at(a.K - 1));
+    while (m) {
+      const int j = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const float d = rdlanef(cd, j);
+      if (d < best.dist_at(a.K - 1))
+        best.push_best_stable(static_cast<int>(i0 + j), d);
+    }
+  }
+
+  const size_t out = (static_cast<size_t>(n) * a.slices + slice) * a.K;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = r * kWave + lane;
+    if (i < a.K) {
+      a.ids[out + i] = best.key[r];
+      a.dists[out + i] = best.dist[r];
+    }
+  }
+}
+
+template <typename BaseT, int LPR, int NCH, int MODE>
+static void launch_bf_r(const BfArgs& args, hipStream_t stream)
+{
+  const dim3 grid(args.Nq * args.slices);
+  if (args.K <= 64)
+    hipLaunchKernelGGL((bf_query_kernel<BaseT, LPR, NCH, 1, MODE>), grid, dim3(kWave), 0, stream,
+                       args);
+  else if (args.K <= 128)
+    hipLaunchKernelGGL((bf_query_kernel<BaseT, LPR, NCH, 2, MODE>), grid, dim3(kWave), 0, stream,
+                       args);
+  else if (args.K <= 256)
+    hipLaunchKernelGGL((bf_query_kernel<BaseT, LPR, NCH, 4, MODE>), grid, dim3(kWave), 0, stream,
+                       args);
+  else
+    throw Error(GGNN_UNSUPPORTED, "bf_query supports k_gt <= 256 in this build");
+}
+
+void launch_bf_query(const BfLaunch& a, hipStream_t stream)
+{
+  if (a.Nq == 0)
+    return;
+  check_vector_layout(a.base, a.D, a.dtype);
+  check_vector_layout(a.query, a.D, a.dtype);
+  GGNN_REQUIRE(a.k_query >= 1 && a.k_query <= 6000, GGNN_INVALID_ARGUMENT,
+               "KQuery must be in [1, 6000]");
+
+  // enough waves to fill the chip: split the base into slices when there are few queries
+  uint32_t slices = 1;
+  const uint32_t target_waves = 256 * 16;
+  if (a.Nq < target_waves)
+    slices = std::min((target_waves + a.Nq - 1) / a.Nq, std::max(1u, a.N_base / 4096u));
+  slices = std::max(1u, std::min(slices, 64u));
+  const uint32_t row_quant = 64;  // multiple of ROWS*STEPS for every configuration
+  uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
+  rows_per_slice = (rows_per_slice + row_quant - 1) / row_quant * row_quant;
+  slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
+  slices = std::max(1u, slices);
+
+  BfArgs args{};
+  args.base = a.base;
+  args.query = a.query;
+  args.D = a.D;
+  args.Nq = a.Nq;
+  args.N_base = a.N_base;
+  args.K = a.k_query;
+  args.slices = slices;
+  args.rows_per_slice = rows_per_slice;
+
+  int32_t* tmp_ids = nullptr;
+  float* tmp_dists = nullptr;
+  if (slices > 1) {
+    const size_t n = static_cast<size_t>(a.Nq) * slices * a.k_query;
+    GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_ids), n * sizeof(int32_t), stream));
+    GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_dists), n * sizeof(float), stream));
+    args.ids = tmp_ids;
+    args.dists = tmp_dists;
+  }
+  else {
+    args.ids = a.ids;
+    args.dists = a.dists;
+  }
+
+#define GGNN_LAUNCH_BF(T, LPR, NCH)                         \
+  do {                                                      \
+    if (a.measure == GGNN_EUCLIDEAN)                        \
+      launch_bf_r<T, LPR, NCH, kL2>(args, stream);          \
+    else                                                    \
+      launch_bf_r<T, LPR, NCH, kCos>(args, stream);         \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_BF);
+#undef GGNN_LAUNCH_BF
+  GGNN_HIP_CHECK(hipGetLastError());
+
+  if (slices > 1) {
+    // slices are in ascending base order, so "lower part first" on ties keeps Q2
+    launch_merge_results(a.Nq, a.k_query, slices, a.k_query, 0, tmp_ids, tmp_dists, a.ids,
+                         a.dists, stream);
+    GGNN_HIP_CHECK(hipFreeAsync(tmp_ids, stream));
+    GGNN_HIP_CHECK(hipFreeAsync(tmp_dists, stream));
+  }
+}
+
+}  // namespace ggnn_amd

@@ -1,0 +1,176 @@
+// Shared host/device definitions of the MI355X GGNN engine (libggnn_amd.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/ggnn_c.h"
+
+namespace ggnn_amd {
+
+constexpr int kWave = 64;
+constexpr int32_t kEmptyKey = -1;
+constexpr uint32_t kLayers = 4;  // reference: graph_config.h:42-44
+constexpr uint32_t kKBlock = 32; // reference: K_BLOCK in query_layer.cu:42, merge_layer.cu:67
+
+struct Error : std::runtime_error {
+  ggnn_status status;
+  Error(ggnn_status s, const std::string& msg) : std::runtime_error(msg), status(s) {}
+};
+
+#define GGNN_HIP_CHECK(expr)                                                                  \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw ::ggnn_amd::Error(_e == hipErrorOutOfMemory ? GGNN_OUT_OF_MEMORY                  \
+                                                        : GGNN_DEVICE_ERROR,                  \
+                              std::string(#expr) + ": " + hipGetErrorString(_e));            \
+  } while (0)
+
+#define GGNN_REQUIRE(cond, status, msg)        \
+  do {                                         \
+    if (!(cond))                               \
+      throw ::ggnn_amd::Error((status), (msg)); \
+  } while (0)
+
+// include/ggnn/base/def.h:37-62 of the reference (host helpers, restated)
+inline uint32_t bit_ceil_u32(uint32_t v)
+{
+  if (v <= 1)
+    return 1;
+  --v;
+  v |= v >> 1;
+  v |= v >> 2;
+  v |= v >> 4;
+  v |= v >> 8;
+  v |= v >> 16;
+  return v + 1;
+}
+inline uint32_t next_multiple32(uint32_t v)
+{
+  return (v + 31u) / 32u * 32u;
+}
+inline size_t align8(size_t s)
+{
+  return (s + 7) / 8 * 8;
+}
+
+extern int g_log_level;
+#define GGNN_LOG(level, ...)                 \
+  do {                                       \
+    if (::ggnn_amd::g_log_level >= (level)) { \
+      std::fprintf(stderr, "[ggnn_amd] ");   \
+      std::fprintf(stderr, __VA_ARGS__);     \
+      std::fprintf(stderr, "\n");            \
+    }                                        \
+  } while (0)
+
+// ---- host-side launchers implemented in the .hip files ---------------------------------------
+struct QueryLaunch {
+  const void* base;
+  const void* query;
+  ggnn_dtype dtype;
+  uint32_t N_base, D, Nq;
+  const int32_t* graph0;
+  uint32_t KBuild;
+  const int32_t* start;
+  uint32_t num_start;
+  const float* nn1_stats;
+  uint32_t k_query;
+  float tau_query;
+  uint32_t max_iterations;
+  ggnn_measure measure;
+  uint32_t shards_per_gpu, on_gpu_shard;
+  int32_t* ids;
+  float* dists;
+  uint32_t* n_dist;
+  uint32_t* n_pop;
+};
+void launch_query(const QueryLaunch& a, hipStream_t stream);
+
+struct BfLaunch {
+  const void* base;
+  const void* query;
+  ggnn_dtype dtype;
+  uint32_t N_base, D, Nq, k_query;
+  ggnn_measure measure;
+  int32_t* ids;
+  float* dists;
+};
+void launch_bf_query(const BfLaunch& a, hipStream_t stream);
+
+struct TopLaunch {
+  const void* base;
+  ggnn_dtype dtype;
+  uint32_t D;
+  ggnn_measure measure;
+  uint32_t KBuild;
+  const int32_t* translation;
+  uint32_t N_layer, S, S_offset, layer;
+  int32_t* graph_layer;
+  float* nn1_dist_buffer;
+};
+void launch_top(const TopLaunch& a, hipStream_t stream);
+
+struct MergeLaunch {
+  const void* base;
+  ggnn_dtype dtype;
+  ggnn_measure measure;
+  ggnn_graph_config cfg;
+  const int32_t* graph_all;
+  const int32_t* translation_all;
+  const int32_t* selection_all;
+  const float* nn1_stats;
+  float tau_build;
+  uint32_t layer_top, layer_btm;
+  int32_t* graph_buffer;
+  float* nn1_dist_buffer;
+  uint32_t* n_dist;
+};
+void launch_merge(const MergeLaunch& a, hipStream_t stream);
+
+struct SymLaunch {
+  const void* base;
+  ggnn_dtype dtype;
+  ggnn_measure measure;
+  uint32_t D, KBuild;
+  const int32_t* graph_layer;
+  const int32_t* translation;
+  uint32_t N_layer;
+  const float* nn1_stats;
+  float tau_build;
+  int32_t* sym_buffer;
+  uint32_t* sym_atomic;
+  uint32_t first_n, count;
+};
+void launch_sym(const SymLaunch& a, hipStream_t stream);
+
+void launch_select(const ggnn_graph_config& cfg, uint32_t layer, const float* nn1_dist_buffer,
+                   const float* rng, int32_t* translation_all, int32_t* selection_all,
+                   hipStream_t stream);
+void launch_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id,
+                    hipStream_t stream);
+void launch_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buffer,
+                             const uint32_t* sym_atomic, int32_t* graph_layer,
+                             hipStream_t stream);
+constexpr uint32_t kStatsBlocks = 1024;
+void launch_nn1_stats(const float* nn1, uint32_t N, float* scratch, float* out,
+                      hipStream_t stream);
+void launch_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, float* dists,
+                               hipStream_t stream);
+void launch_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                          uint32_t id_offset_per_part, const int32_t* parts_ids,
+                          const float* parts_dists, int32_t* ids_out, float* dists_out,
+                          hipStream_t stream);
+
+// host layout math (graph_config.cpp)
+void graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild, ggnn_graph_config* out);
+void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_t* cache_size,
+                  uint32_t* sorted_size);
+uint32_t merge_sorted_size(uint32_t KBuild);
+uint32_t sym_sorted_size(uint32_t KBuild);
+
+}  // namespace ggnn_amd

@@ -1,0 +1,354 @@
+// Small construction kernels: top, select (+ uniform RNG), sym_buffer_merge, nn1 statistics.
+#include "traversal.hpp"
+
+#include <cfloat>
+
+namespace ggnn_amd {
+
+// ---------------------------------------------------------------------------------------------
+// top: brute-force kNN inside the point's own segment.
+// Reference: TopMergeKernel::operator(), src/ggnn/construction/top_merge_layer.cu:40-82.
+// One wave per point; distances of all segment members are computed 64/LPR rows at a time, the
+// K best are selected by a stable rank (KBestList::add_unique semantics, k_best_list.cuh:77-109).
+// ---------------------------------------------------------------------------------------------
+struct TopArgs {
+  const void* base;
+  const int32_t* translation;
+  int32_t* graph;
+  float* nn1_dist_buffer;
+  uint32_t D, KBuild, N_layer, S, S_offset, layer, cap;
+};
+
+template <typename BaseT, int LPR, int NCH, int MODE>
+__global__ void __launch_bounds__(kWave) top_kernel(const TopArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  // "known" region doubles as [cap] dists + [cap] ids
+  const WaveLds lds(lds_raw, 2 * a.cap);
+  float* all_d = reinterpret_cast<float*>(lds.known);
+  int* all_id = lds.known + a.cap;
+  const int lane = threadIdx.x;
+  const uint32_t n = blockIdx.x;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const uint32_t K = a.KBuild;
+
+  const int m = (!a.layer) ? static_cast<int>(n) : a.translation[n];
+  DistEngine<BaseT, LPR, NCH> de;
+  de.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D);
+
+  // segment bounds, top_merge_layer.cu:51-58
+  const uint32_t S_plus_offset = a.S_offset * (a.S + 1);
+  const uint32_t S_actual = (!a.layer && n < S_plus_offset) ? a.S + 1 : a.S;
+  const uint32_t start = (a.layer || n < S_plus_offset)
+                             ? (n / S_actual) * S_actual
+                             : S_plus_offset + ((n - S_plus_offset) / S_actual) * S_actual;
+  const uint32_t end = start + S_actual;
+
+  const int32_t* tr = a.layer ? a.translation : nullptr;
+  uint32_t count = 0;
+  for (uint32_t b0 = start; b0 < end; b0 += kKBlock) {
+    const uint32_t other_n = b0 + lane;
+    bool valid = lane < (int)kKBlock && other_n < end;
+    if (valid) {
+      const int other_m = tr ? tr[other_n] : static_cast<int>(other_n);
+      valid = (other_m != m);  // top_merge_layer.cu:64-65
+    }
+    const unsigned long long surv = __ballot(valid);
+    const int nsurv = __popcll(surv);
+    if (!nsurv)
+      continue;
+    __syncthreads();
+    if (valid)
+      lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = static_cast<int>(other_n);
+    __syncthreads();
+    compute_distances<MODE>(de, lds, nsurv, tr);
+    __syncthreads();
+    if (lane < nsurv) {
+      all_d[count + lane] = lds.cd0[lane];
+      all_id[count + lane] = lds.ckeys[lane];
+    }
+    count += nsurv;
+  }
+  __syncthreads();
+
+  int32_t* row = a.graph + static_cast<size_t>(n) * K;
+  float nn1 = inf_f();  // s_dists[1] when fewer than two candidates exist
+  for (uint32_t i = lane; i < count; i += kWave) {
+    const float d = all_d[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      const float dj = all_d[j];
+      rank += (dj < d) || (dj == d && j < i);
+    }
+    if (rank < K)
+      row[rank] = all_id[i];
+    if (rank == 1)
+      nn1 = d;
+  }
+  for (uint32_t k = count + lane; k < K; k += kWave)
+    row[k] = kEmptyKey;
+  // exactly one lane (if any) holds rank 1
+  const unsigned long long has = __ballot(nn1 != inf_f());
+  if (has)
+    nn1 = rdlanef(nn1, __ffsll(static_cast<long long>(has)) - 1);
+  if (MODE == kL2)
+    nn1 = sqrtf(nn1);  // top_merge_layer.cu:76-81 (Q4)
+  if (lane == 0)
+    a.nn1_dist_buffer[n] = nn1;
+}
+
+void launch_top(const TopLaunch& a, hipStream_t stream)
+{
+  if (!a.N_layer)
+    return;
+  check_vector_layout(a.base, a.D, a.dtype);
+  TopArgs args{};
+  args.base = a.base;
+  args.translation = a.translation;
+  args.graph = a.graph_layer;
+  args.nn1_dist_buffer = a.nn1_dist_buffer;
+  args.D = a.D;
+  args.KBuild = a.KBuild;
+  args.N_layer = a.N_layer;
+  args.S = a.S;
+  args.S_offset = a.S_offset;
+  args.layer = a.layer;
+  args.cap = (a.S + 1 + 3) / 4 * 4;
+  const size_t lds = wave_lds_bytes(2 * args.cap);
+  GGNN_REQUIRE(lds <= 64 * 1024, GGNN_UNSUPPORTED, "segment too large for the top kernel");
+#define GGNN_LAUNCH_TOP(T, LPR, NCH)                                                          \
+  do {                                                                                        \
+    if (a.measure == GGNN_EUCLIDEAN)                                                          \
+      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kL2>), dim3(a.N_layer), dim3(kWave), lds,   \
+                         stream, args);                                                       \
+    else                                                                                      \
+      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kCos>), dim3(a.N_layer), dim3(kWave), lds,  \
+                         stream, args);                                                       \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_TOP);
+#undef GGNN_LAUNCH_TOP
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// select: weighted reservoir sampling of the points promoted to the next layer.
+// Reference: WRSSelectionKernel::operator(), src/ggnn/construction/wrs_select_layer.cu:41-102
+// (cub::BlockRadixSort<float,128,2,int> descending, blocked -> striped) restated as a stable
+// rank over the radix-key order.  One wave per lower segment.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t radix_key_f(float f)
+{
+  if (f == 0.0f)
+    f = 0.0f;  // CUB 2.x: -0.0 and +0.0 are equivalent
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct SelectArgs {
+  const float* nn1_dist_buffer;
+  const float* rng;
+  const int32_t* translation_layer;
+  int32_t* selection_up;
+  int32_t* translation_up;
+  uint32_t Sglob, S, S_offset, G, SG, SG_offset, layer;
+};
+
+__global__ void __launch_bounds__(kWave) select_kernel(const SelectArgs a)
+{
+  constexpr uint32_t kBlock = 128, kItems = 2;  // wrs_select_layer.cuh:40-41
+  __shared__ uint32_t s_key[kBlock * kItems];
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  const uint32_t S_current = a.S + (b < a.S_offset);
+  const uint32_t start = b * a.S + min(b, a.S_offset);
+
+  for (uint32_t i = lane; i < S_current; i += kWave) {
+    const uint32_t n = start + i;
+    const float e = (-1 * logf(a.rng[n])) / (a.nn1_dist_buffer[n] + FLT_EPSILON);
+    s_key[i] = radix_key_f(e);
+  }
+  __syncthreads();
+
+  const uint32_t upper_segment = b / a.G;
+  const uint32_t nth = b - upper_segment * a.G;
+  const uint32_t num_selected = a.SG + (nth < a.SG_offset);
+  const uint32_t dest = upper_segment * a.Sglob + nth * a.SG + min(nth, a.SG_offset);
+
+  for (uint32_t i = lane; i < S_current; i += kWave) {
+    const uint32_t k = s_key[i];
+    const uint32_t pos = (i % kBlock) * kItems + i / kBlock;  // blocked arrangement order
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < S_current; ++j) {
+      const uint32_t kj = s_key[j];
+      const uint32_t pj = (j % kBlock) * kItems + j / kBlock;
+      rank += (kj > k) || (kj == k && pj < pos);
+    }
+    if (rank < num_selected) {
+      const int n = static_cast<int>(start + i);
+      a.selection_up[dest + rank] = n;
+      a.translation_up[dest + rank] = (!a.layer) ? n : a.translation_layer[n];
+    }
+  }
+  // fewer points than requested (the reference would select padding entries): mark as empty
+  for (uint32_t s = S_current + lane; s < num_selected; s += kWave) {
+    a.selection_up[dest + s] = kEmptyKey;
+    a.translation_up[dest + s] = kEmptyKey;
+  }
+}
+
+void launch_select(const ggnn_graph_config& c, uint32_t layer, const float* nn1_dist_buffer,
+                   const float* rng, int32_t* translation_all, int32_t* selection_all,
+                   hipStream_t stream)
+{
+  GGNN_REQUIRE(layer + 1 < kLayers, GGNN_INVALID_ARGUMENT, "select needs layer < L-1");
+  SelectArgs a{};
+  a.nn1_dist_buffer = nn1_dist_buffer;
+  a.rng = rng;
+  a.translation_layer = translation_all + c.STs_offsets[layer];
+  a.selection_up = selection_all + c.STs_offsets[layer + 1];
+  a.translation_up = translation_all + c.STs_offsets[layer + 1];
+  a.Sglob = c.S;
+  a.S = layer ? c.S : c.S0;
+  a.S_offset = layer ? 0 : c.S0_off;
+  a.G = c.G;
+  a.SG = c.SG;
+  a.SG_offset = c.SG_off;
+  a.layer = layer;
+  // wrs_select_layer.cuh:47-48
+  GGNN_REQUIRE(a.S + (a.S_offset > 0) <= 256 && a.SG + (a.SG_offset > 0) <= 256,
+               GGNN_UNSUPPORTED, "segment size exceeds the selection kernel's capacity");
+  hipLaunchKernelGGL(select_kernel, dim3(c.Bs[layer]), dim3(kWave), 0, stream, a);
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+// counter-based uniform (0,1] generator (stand-in for curandGenerateUniform, which is XORWOW
+// with an ordering that cannot be reproduced; parity of select() is tested with injected rng)
+__global__ void uniform_kernel(float* out, uint32_t n, uint64_t seed, uint64_t stream_id)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (stream_id * 0x100000000ull + i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  out[i] = (static_cast<float>(static_cast<uint32_t>(z >> 40)) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+void launch_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id, hipStream_t stream)
+{
+  if (!n)
+    return;
+  hipLaunchKernelGGL(uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, seed,
+                     stream_id);
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// sym_buffer_merge: src/ggnn/construction/sym_buffer_merge_layer.cu:36-99.  One thread per
+// point; the point's sym_buffer row is the working list (it is scratch after this kernel).
+// ---------------------------------------------------------------------------------------------
+__global__ void sym_buffer_merge_kernel(uint32_t K, uint32_t N, int32_t* sym_buffer,
+                                        const uint32_t* sym_atomic, int32_t* graph)
+{
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N)
+    return;
+  const uint32_t KF = K / 2, KL = K - KF;
+  int32_t* s_sym = sym_buffer + static_cast<size_t>(n) * KF;
+  int32_t* g_row = graph + static_cast<size_t>(n) * K + KL;
+  uint32_t num_links = sym_atomic[n];
+  for (uint32_t i = 0; i < KF && num_links < KF; ++i) {
+    const int32_t r_graph = g_row[i];
+    bool found = false;
+    for (uint32_t kf = 0; kf < KF; ++kf)
+      found |= (s_sym[kf] == r_graph);
+    if (!found) {
+      s_sym[num_links] = r_graph;
+      ++num_links;
+    }
+  }
+  for (uint32_t kf = 0; kf < KF; ++kf) {
+    const int32_t res = s_sym[kf];
+    g_row[kf] = (res >= 0) ? res : static_cast<int32_t>(n);
+  }
+}
+
+void launch_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buffer,
+                             const uint32_t* sym_atomic, int32_t* graph_layer, hipStream_t stream)
+{
+  if (!N_layer)
+    return;
+  hipLaunchKernelGGL(sym_buffer_merge_kernel, dim3((N_layer + 127) / 128), dim3(128), 0, stream,
+                     KBuild, N_layer, sym_buffer, sym_atomic, graph_layer);
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn1 statistics: {mean, max} of nn1_dist_buffer[0,N).
+// Reference: computeNN1Stats + divide, graph_construction.cu:381-393,79-83 (cub::DeviceReduce,
+// summation order unpinned).  Two-pass deterministic tree reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nn1_partial_kernel(const float* v, uint32_t N,
+                                                          float* scratch)
+{
+  __shared__ float s_sum[256];
+  __shared__ float s_max[256];
+  float sum = 0.f, mx = -inf_f();
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const float x = v[i];
+    sum += x;
+    mx = fmaxf(mx, x);
+  }
+  s_sum[threadIdx.x] = sum;
+  s_max[threadIdx.x] = mx;
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (!threadIdx.x) {
+    scratch[blockIdx.x] = s_sum[0];
+    scratch[gridDim.x + blockIdx.x] = s_max[0];
+  }
+}
+
+__global__ void __launch_bounds__(256) nn1_final_kernel(const float* scratch, uint32_t blocks,
+                                                        uint32_t N, float* out)
+{
+  __shared__ float s_sum[256];
+  __shared__ float s_max[256];
+  float sum = 0.f, mx = -inf_f();
+  for (uint32_t i = threadIdx.x; i < blocks; i += 256) {
+    sum += scratch[i];
+    mx = fmaxf(mx, scratch[blocks + i]);
+  }
+  s_sum[threadIdx.x] = sum;
+  s_max[threadIdx.x] = mx;
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (!threadIdx.x) {
+    out[0] = s_sum[0] / static_cast<float>(N);  // divide<<<1,1>>>: only element 0
+    out[1] = s_max[0];
+  }
+}
+
+void launch_nn1_stats(const float* nn1, uint32_t N, float* scratch, float* out, hipStream_t stream)
+{
+  GGNN_REQUIRE(N > 0, GGNN_INVALID_ARGUMENT, "nn1 statistics of an empty buffer");
+  const uint32_t blocks = std::min(kStatsBlocks, (N + 255) / 256);
+  hipLaunchKernelGGL(nn1_partial_kernel, dim3(blocks), dim3(256), 0, stream, nn1, N, scratch);
+  hipLaunchKernelGGL(nn1_final_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, N, out);
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ggnn_amd

@@ -1,0 +1,973 @@
+// Engine behind the C-ABI (include/ggnn_c.h): shard residency, build schedule, query / bf_query
+// drivers.  Replaces, for the hot path only, GGNNImpl (src/ggnn/base/ggnn.cu:124-413),
+// GPUInstance::build/query (src/ggnn/base/gpu_instance.cu:499-584, 626-790) and
+// GraphConstructionImpl::build/refine (src/ggnn/construction/graph_construction.cu:128-147).
+//
+// MI355X-first choices: every shard of the base and its graph stay resident in HBM (288 GB), so
+// the reference's GPU<->CPU<->disk swapping is not reproduced; one engine drives one GPU
+// (multi-GPU = one process per GPU, shards exchanged with an RCCL all-gather, see
+// ggnn_amd/distributed.py and DESIGN.md).
+#include <algorithm>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+
+namespace ggnn_amd {
+
+namespace {
+
+struct DeviceBuffer {
+  void* p{nullptr};
+  size_t bytes{0};
+  DeviceBuffer() = default;
+  explicit DeviceBuffer(size_t n) { alloc(n); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : p(o.p), bytes(o.bytes)
+  {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept
+  {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+  void alloc(size_t n)
+  {
+    release();
+    if (n) {
+      GGNN_HIP_CHECK(hipMalloc(&p, n));
+      bytes = n;
+    }
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
+struct EventTimer {
+  hipEvent_t a{}, b{};
+  hipStream_t s;
+  explicit EventTimer(hipStream_t stream) : s(stream)
+  {
+    GGNN_HIP_CHECK(hipEventCreate(&a));
+    GGNN_HIP_CHECK(hipEventCreate(&b));
+    GGNN_HIP_CHECK(hipEventRecord(a, s));
+  }
+  float stop()
+  {
+    float ms = 0.f;
+    GGNN_HIP_CHECK(hipEventRecord(b, s));
+    GGNN_HIP_CHECK(hipEventSynchronize(b));
+    GGNN_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
+  ~EventTimer()
+  {
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+};
+
+size_t dtype_size(ggnn_dtype t)
+{
+  return t == GGNN_F32 ? 4 : 1;
+}
+
+// graph pool of one shard, reference layout (src/ggnn/base/graph.cpp:48-91):
+// [N_all x K int32 graph][ST_all int32 translation][ST_all int32 selection][2 float nn1_stats]
+struct Shard {
+  uint32_t global_id{0};
+  DeviceBuffer pool;
+  int32_t* graph{nullptr};
+  int32_t* translation{nullptr};
+  int32_t* selection{nullptr};
+  float* nn1_stats{nullptr};
+  bool ready{false};
+
+  static size_t pool_bytes(const ggnn_graph_config& c)
+  {
+    return (static_cast<size_t>(c.N_all) * c.KBuild + 2 * static_cast<size_t>(c.ST_all)) * 4 +
+           2 * sizeof(float);
+  }
+  void allocate(const ggnn_graph_config& c)
+  {
+    pool.alloc(align8(pool_bytes(c)));
+    graph = pool.as<int32_t>();
+    translation = graph + static_cast<size_t>(c.N_all) * c.KBuild;
+    selection = translation + c.ST_all;
+    nn1_stats = reinterpret_cast<float*>(selection + c.ST_all);
+  }
+};
+
+}  // namespace
+}  // namespace ggnn_amd
+
+using namespace ggnn_amd;
+
+struct ggnn_handle {
+  // configuration (GGNNConfig, ggnn.cu:52-59)
+  std::filesystem::path graph_dir{};
+  size_t cpu_memory_limit{static_cast<size_t>(-1)};
+  size_t reserved_gpu_memory{0};
+  std::vector<int> gpu_ids{};
+  uint32_t N_shard{0};
+  bool return_results_on_gpu{false};
+  bool collect_counters{false};
+
+  // base
+  const void* base_src{nullptr};
+  ggnn_location base_loc{GGNN_CPU};
+  int base_gpu{0};
+  std::vector<uint8_t> base_host_copy;
+  DeviceBuffer base_dev_copy;
+  const void* d_base{nullptr};
+  uint64_t base_N{0};
+  uint32_t base_D{0};
+  ggnn_dtype base_dtype{GGNN_F32};
+  bool base_set{false};
+
+  // graph
+  bool prepared{false};
+  int device{0};
+  hipStream_t stream{nullptr};
+  ggnn_graph_config cfg{};
+  uint32_t num_shards{0};
+  std::vector<Shard> shards;
+
+  // tracing
+  float build_ms{0.f}, query_ms{0.f}, bf_ms{0.f};
+  uint64_t last_n_dist{0}, last_n_pop{0};
+
+  std::string last_error;
+
+  ~ggnn_handle()
+  {
+    if (stream)
+      (void)hipStreamDestroy(stream);
+  }
+
+  void activate()
+  {
+    GGNN_HIP_CHECK(hipSetDevice(device));
+    if (!stream)
+      GGNN_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  }
+
+  void select_device()
+  {
+    GGNN_REQUIRE(gpu_ids.size() <= 1, GGNN_UNSUPPORTED,
+                 "one engine drives one GPU; for several GPUs run one process per GPU "
+                 "(ggnn_amd.distributed.ShardedGGNN, RCCL all-gather of the candidates)");
+    if (gpu_ids.empty()) {
+      int d = 0;
+      GGNN_HIP_CHECK(hipGetDevice(&d));  // ggnn.cu:172-176
+      device = d;
+    }
+    else
+      device = gpu_ids[0];
+    activate();
+  }
+
+  // base.referenceOnGPU (dataset.cu:236-300): make the base resident on the engine's GPU
+  void stage_base()
+  {
+    if (d_base)
+      return;
+    GGNN_REQUIRE(base_set, GGNN_INVALID_STATE, "The base needs to be set first.");
+    const size_t bytes = base_N * base_D * dtype_size(base_dtype);
+    if (base_loc == GGNN_GPU && base_gpu == device && base_dev_copy.p == nullptr) {
+      d_base = base_src;  // borrowed device memory on the right GPU
+      return;
+    }
+    if (base_dev_copy.p && base_gpu == device) {
+      d_base = base_dev_copy.p;
+      return;
+    }
+    DeviceBuffer staged(bytes);
+    const void* src = base_dev_copy.p ? base_dev_copy.p : base_src;
+    GGNN_HIP_CHECK(hipMemcpyAsync(staged.p, src, bytes,
+                                  base_loc == GGNN_GPU ? hipMemcpyDeviceToDevice
+                                                       : hipMemcpyHostToDevice,
+                                  stream));
+    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+    base_dev_copy = std::move(staged);
+    base_gpu = device;
+    base_loc = GGNN_GPU;
+    base_host_copy.clear();
+    base_host_copy.shrink_to_fit();
+    d_base = base_dev_copy.p;
+  }
+
+  const void* shard_base(uint32_t shard) const
+  {
+    return static_cast<const uint8_t*>(d_base) +
+           static_cast<size_t>(shard) * cfg.N * base_D * dtype_size(base_dtype);
+  }
+
+  // GGNNImpl::prepare, ggnn.cu:154-203
+  void prepare(uint32_t KBuild)
+  {
+    GGNN_REQUIRE(!prepared, GGNN_INVALID_STATE, "A graph has already been built or loaded.");
+    GGNN_REQUIRE(base_set, GGNN_INVALID_STATE,
+                 "The base needs to be set before building a graph.");
+    uint64_t n = base_N;
+    if (N_shard > 0) {
+      GGNN_REQUIRE(base_N % N_shard == 0, GGNN_INVALID_ARGUMENT,
+                   "The base dataset needs to be evenly divisible by the shard size.");
+      n = N_shard;
+    }
+    GGNN_REQUIRE(n > 0 && n < 0x7fffffffull, GGNN_INVALID_ARGUMENT,
+                 "shard size must be in [1, 2^31-1)");
+    GGNN_REQUIRE(base_D >= 1 && base_D <= 4096, GGNN_INVALID_ARGUMENT, "D must be in [1, 4096]");
+    GGNN_REQUIRE(KBuild >= 2 && KBuild <= 512, GGNN_INVALID_ARGUMENT,
+                 "KBuild must be in [2, 512]");
+    select_device();
+    const uint64_t spg = base_N / n;  // one GPU: shards per GPU = all shards
+    GGNN_REQUIRE(n * spg == base_N, GGNN_INVALID_ARGUMENT,
+                 "base.N needs to be evenly divisible by (N_shard x num_gpus).");
+    GGNN_REQUIRE(base_N < 0x7fffffffull, GGNN_INVALID_ARGUMENT,
+                 "ids are int32: at most 2^31-1 base points per engine");
+    graph_config_init(static_cast<uint32_t>(n), base_D, KBuild, &cfg);
+    num_shards = static_cast<uint32_t>(spg);
+    stage_base();
+    shards.clear();
+    shards.resize(num_shards);
+    for (uint32_t i = 0; i < num_shards; ++i) {
+      shards[i].global_id = i;
+      shards[i].allocate(cfg);
+    }
+    prepared = true;
+    GGNN_LOG(1, "prepare: N_shard=%u shards=%u D=%u K=%u G=%u S=%u S0=%u S0_off=%u N_all=%u",
+             cfg.N, num_shards, cfg.D, cfg.KBuild, cfg.G, cfg.S, cfg.S0, cfg.S0_off, cfg.N_all);
+  }
+
+  // GraphConstructionImpl::build / refine, graph_construction.cu:128-147
+  void build(uint32_t KBuild, float tau_build, uint32_t refinement_iterations,
+             ggnn_measure measure)
+  {
+    prepare(KBuild);
+    const uint32_t N = cfg.N, K = cfg.KBuild, KF = cfg.KF;
+    // scratch (GraphBuffer, graph_buffer.cu:38-81); not overlapped -- HBM is plentiful
+    DeviceBuffer nn1_dist(static_cast<size_t>(N) * 4), graph_buffer(static_cast<size_t>(N) * K * 4),
+        rng(static_cast<size_t>(N) * 4), sym_buffer(static_cast<size_t>(N) * KF * 4),
+        sym_atomic(static_cast<size_t>(N) * 4), stats_scratch(2 * kStatsBlocks * 4);
+    build_ms = 0.f;
+    uint64_t rng_calls = 0;
+
+    for (uint32_t si = 0; si < num_shards; ++si) {
+      Shard& sh = shards[si];
+      const void* base = shard_base(si);
+      EventTimer timer(stream);
+
+      auto layer_graph = [&](uint32_t l) {
+        return sh.graph + static_cast<size_t>(cfg.Ns_offsets[l]) * K;
+      };
+      auto layer_tr = [&](uint32_t l) -> int32_t* {
+        return l ? sh.translation + cfg.STs_offsets[l] : nullptr;
+      };
+      auto do_merge = [&](uint32_t top, uint32_t btm) {
+        if (top == btm) {
+          TopLaunch t{base,        base_dtype,          base_D,
+                      measure,     K,                   layer_tr(btm),
+                      cfg.Ns[btm], btm ? cfg.S : cfg.S0, btm ? 0u : cfg.S0_off,
+                      btm,         layer_graph(btm),    nn1_dist.as<float>()};
+          launch_top(t, stream);
+        }
+        else {
+          MergeLaunch m{base,
+                        base_dtype,
+                        measure,
+                        cfg,
+                        sh.graph,
+                        sh.translation,
+                        sh.selection,
+                        sh.nn1_stats,
+                        tau_build,
+                        top,
+                        btm,
+                        graph_buffer.as<int32_t>(),
+                        nn1_dist.as<float>(),
+                        nullptr};
+          launch_merge(m, stream);
+          GGNN_HIP_CHECK(hipMemcpyAsync(layer_graph(btm), graph_buffer.p,
+                                        static_cast<size_t>(cfg.Ns[btm]) * K * 4,
+                                        hipMemcpyDeviceToDevice, stream));
+        }
+        if (!btm)
+          launch_nn1_stats(nn1_dist.as<float>(), N, stats_scratch.as<float>(), sh.nn1_stats,
+                           stream);
+      };
+      auto do_select = [&](uint32_t layer) {
+        launch_uniform(rng.as<float>(), cfg.Ns[layer], 1234ull, rng_calls++, stream);
+        launch_select(cfg, layer, nn1_dist.as<float>(), rng.as<float>(), sh.translation,
+                      sh.selection, stream);
+      };
+      auto do_sym = [&](uint32_t layer) {
+        GGNN_HIP_CHECK(hipMemsetAsync(sym_buffer.p, 0xff,
+                                      static_cast<size_t>(cfg.Ns[layer]) * KF * 4, stream));
+        GGNN_HIP_CHECK(
+            hipMemsetAsync(sym_atomic.p, 0, static_cast<size_t>(cfg.Ns[layer]) * 4, stream));
+        SymLaunch s{base,
+                    base_dtype,
+                    measure,
+                    base_D,
+                    K,
+                    layer_graph(layer),
+                    layer_tr(layer),
+                    cfg.Ns[layer],
+                    sh.nn1_stats,
+                    tau_build,
+                    sym_buffer.as<int32_t>(),
+                    sym_atomic.as<uint32_t>(),
+                    0,
+                    cfg.Ns[layer]};
+        launch_sym(s, stream);
+        launch_sym_buffer_merge(K, cfg.Ns[layer], sym_buffer.as<int32_t>(),
+                                sym_atomic.as<uint32_t>(), layer_graph(layer), stream);
+      };
+
+      // no selection/translation on layer 0; start from a defined state
+      GGNN_HIP_CHECK(hipMemsetAsync(sh.translation, 0xff,
+                                    2 * static_cast<size_t>(cfg.ST_all) * 4, stream));
+
+      for (uint32_t top = 0; top < kLayers; ++top) {
+        for (uint32_t btm = top; btm != 0xffffffffu; --btm) {
+          do_merge(top, btm);
+          if (top < kLayers - 1 && top == btm)
+            do_select(top);
+          do_sym(btm);
+        }
+      }
+      for (uint32_t r = 0; r < refinement_iterations; ++r) {
+        for (uint32_t layer = kLayers - 2; layer != 0xffffffffu; --layer) {
+          do_merge(kLayers - 1, layer);
+          do_sym(layer);
+        }
+      }
+      const float ms = timer.stop();
+      build_ms += ms;
+      sh.ready = true;
+      GGNN_LOG(0, "build(): part %u => %.3f s [%u points -> %.3f us/point]", si, ms / 1000.f, N,
+               ms * 1000.f / static_cast<float>(N));
+    }
+    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  struct Staged {
+    const void* ptr{nullptr};
+    DeviceBuffer owned;
+  };
+  Staged stage_query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc)
+  {
+    GGNN_REQUIRE(dtype == base_dtype, GGNN_INVALID_ARGUMENT,
+                 "query data type does not match base data type");
+    GGNN_REQUIRE(D == base_D, GGNN_INVALID_ARGUMENT, "query dimension does not match the base");
+    GGNN_REQUIRE(Nq < 0xffffffffull, GGNN_INVALID_ARGUMENT, "too many queries");
+    Staged s;
+    if (!Nq)
+      return s;
+    GGNN_REQUIRE(q != nullptr, GGNN_INVALID_ARGUMENT, "query pointer is null");
+    if (loc == GGNN_GPU) {
+      s.ptr = q;
+      return s;
+    }
+    const size_t bytes = Nq * D * dtype_size(dtype);
+    s.owned.alloc(bytes);
+    GGNN_HIP_CHECK(hipMemcpyAsync(s.owned.p, q, bytes, hipMemcpyHostToDevice, stream));
+    s.ptr = s.owned.p;
+    return s;
+  }
+
+  void copy_out(const void* d_src, void* dst, size_t bytes, ggnn_location loc)
+  {
+    if (!bytes)
+      return;
+    GGNN_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes,
+                                  loc == GGNN_GPU ? hipMemcpyDeviceToDevice
+                                                  : hipMemcpyDeviceToHost,
+                                  stream));
+  }
+
+  // GGNNImpl::queryImpl + GPUInstance::query, ggnn.cu:278-330, gpu_instance.cu:626-743
+  void query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
+             uint32_t k_query, float tau_query, uint32_t max_iterations, ggnn_measure measure,
+             int32_t* ids_out, float* dists_out, ggnn_location out_loc)
+  {
+    GGNN_REQUIRE(prepared && !shards.empty() && shards[0].ready, GGNN_INVALID_STATE,
+                 "There is no graph to query.");
+    activate();
+    Staged sq = stage_query(q, Nq, D, dtype, loc);
+    query_ms = 0.f;
+    last_n_dist = last_n_pop = 0;
+    if (!Nq)
+      return;
+    const uint32_t nq = static_cast<uint32_t>(Nq);
+    const size_t row = static_cast<size_t>(k_query) * num_shards;
+    // results [Nq, K*shards] (gpu_instance.cu:643-645); written straight into the caller's
+    // device buffer when that is what was asked for
+    const bool direct = (out_loc == GGNN_GPU);
+    DeviceBuffer r_ids, r_dists;
+    int32_t* d_ids = ids_out;
+    float* d_dists = dists_out;
+    if (!direct) {
+      r_ids.alloc(nq * row * 4);
+      r_dists.alloc(nq * row * 4);
+      d_ids = r_ids.as<int32_t>();
+      d_dists = r_dists.as<float>();
+    }
+    DeviceBuffer c_dist, c_pop;
+    if (collect_counters) {
+      c_dist.alloc(static_cast<size_t>(nq) * 4);
+      c_pop.alloc(static_cast<size_t>(nq) * 4);
+    }
+    std::vector<uint32_t> h_cnt;
+    for (uint32_t si = 0; si < num_shards; ++si) {
+      const Shard& sh = shards[si];
+      QueryLaunch ql{shard_base(si),
+                     sq.ptr,
+                     base_dtype,
+                     cfg.N,
+                     base_D,
+                     nq,
+                     sh.graph,
+                     cfg.KBuild,
+                     sh.translation + cfg.STs_offsets[kLayers - 1],
+                     cfg.S,
+                     sh.nn1_stats,
+                     k_query,
+                     tau_query,
+                     max_iterations,
+                     measure,
+                     num_shards,
+                     si,
+                     d_ids,
+                     d_dists,
+                     c_dist.as<uint32_t>(),
+                     c_pop.as<uint32_t>()};
+      EventTimer timer(stream);
+      launch_query(ql, stream);
+      const float ms = timer.stop();
+      query_ms += ms;
+      GGNN_LOG(0, "query part %u => ms: %.3f [%u points query -> %.3f us/point]", si, ms, nq,
+               ms * 1000.f / static_cast<float>(nq));
+      if (collect_counters) {
+        h_cnt.resize(nq);
+        GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_dist.p, nq * 4ull, hipMemcpyDeviceToHost));
+        for (uint32_t v : h_cnt)
+          last_n_dist += v;
+        GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_pop.p, nq * 4ull, hipMemcpyDeviceToHost));
+        for (uint32_t v : h_cnt)
+          last_n_pop += v;
+      }
+    }
+    if (num_shards > 1)
+      launch_sort_shard_results(nq, static_cast<uint32_t>(row), d_ids, d_dists, stream);
+    if (!direct) {
+      // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, d_ids, row * 4, k_query * 4ull, nq,
+                                      hipMemcpyDeviceToHost, stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, d_dists, row * 4, k_query * 4ull,
+                                      nq, hipMemcpyDeviceToHost, stream));
+    }
+    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  // GGNNImpl::bfQueryImpl, ggnn.cu:332-390
+  void bf_query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
+                uint32_t k_gt, ggnn_measure measure, int32_t* ids_out, float* dists_out,
+                ggnn_location out_loc)
+  {
+    GGNN_REQUIRE(base_set, GGNN_INVALID_STATE,
+                 "There is no base dataset loaded which could be queried.");
+    if (!prepared)
+      select_device();
+    else
+      activate();
+    stage_base();
+    Staged sq = stage_query(q, Nq, D, dtype, loc);
+    bf_ms = 0.f;
+    if (!Nq)
+      return;
+    const uint32_t nq = static_cast<uint32_t>(Nq);
+    const bool direct = (out_loc == GGNN_GPU);
+    DeviceBuffer r_ids, r_dists;
+    int32_t* d_ids = ids_out;
+    float* d_dists = dists_out;
+    if (!direct) {
+      r_ids.alloc(static_cast<size_t>(nq) * k_gt * 4);
+      r_dists.alloc(static_cast<size_t>(nq) * k_gt * 4);
+      d_ids = r_ids.as<int32_t>();
+      d_dists = r_dists.as<float>();
+    }
+    BfLaunch bl{d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), base_D, nq, k_gt,
+                measure, d_ids, d_dists};
+    EventTimer timer(stream);
+    launch_bf_query(bl, stream);
+    bf_ms = timer.stop();
+    GGNN_LOG(0, "brute-force query: => ms: %.3f [%u points query -> %.3f us/point]", bf_ms, nq,
+             bf_ms * 1000.f / static_cast<float>(nq));
+    if (!direct) {
+      copy_out(d_ids, ids_out, static_cast<size_t>(nq) * k_gt * 4, out_loc);
+      copy_out(d_dists, dists_out, static_cast<size_t>(nq) * k_gt * 4, out_loc);
+    }
+    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  std::filesystem::path part_file(uint32_t shard) const
+  {
+    // gpu_instance.cu:86-115 (part_<global_shard_id>.ggnn)
+    return graph_dir / ("part_" + std::to_string(shard) + ".ggnn");
+  }
+
+  void store()
+  {
+    GGNN_REQUIRE(prepared && !shards.empty() && shards[0].ready, GGNN_INVALID_STATE,
+                 "There is no graph to store.");
+    activate();
+    if (graph_dir.empty())
+      graph_dir = std::filesystem::current_path();
+    std::vector<char> host(Shard::pool_bytes(cfg));
+    for (const Shard& sh : shards) {
+      GGNN_HIP_CHECK(hipMemcpy(host.data(), sh.pool.p, host.size(), hipMemcpyDeviceToHost));
+      std::ofstream f(part_file(sh.global_id), std::ios::binary | std::ios::trunc);
+      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "cannot open " + part_file(sh.global_id).string());
+      f.write(host.data(), static_cast<std::streamsize>(host.size()));
+      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short write to " + part_file(sh.global_id).string());
+    }
+  }
+
+  void load(uint32_t KBuild)
+  {
+    GGNN_REQUIRE(base_set, GGNN_INVALID_STATE,
+                 "The base needs to be set before loading a graph.");
+    if (graph_dir.empty())
+      graph_dir = std::filesystem::current_path();
+    prepare(KBuild);
+    std::vector<char> host(Shard::pool_bytes(cfg));
+    for (Shard& sh : shards) {
+      const auto file = part_file(sh.global_id);
+      std::error_code ec;
+      const auto sz = std::filesystem::file_size(file, ec);
+      // the reference validates by file size only (gpu_instance.cu:413-415)
+      GGNN_REQUIRE(!ec && sz == host.size(), GGNN_IO_ERROR,
+                   "missing or mismatching graph file " + file.string());
+      std::ifstream f(file, std::ios::binary);
+      f.read(host.data(), static_cast<std::streamsize>(host.size()));
+      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short read from " + file.string());
+      GGNN_HIP_CHECK(hipMemcpy(sh.pool.p, host.data(), host.size(), hipMemcpyHostToDevice));
+      sh.ready = true;
+    }
+  }
+};
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename F>
+ggnn_status guarded(ggnn_t* h, F&& f)
+{
+  try {
+    f();
+    return GGNN_OK;
+  }
+  catch (const Error& e) {
+    (h ? h->last_error : g_create_error) = e.what();
+    return e.status;
+  }
+  catch (const std::bad_alloc&) {
+    (h ? h->last_error : g_create_error) = "out of host memory";
+    return GGNN_OUT_OF_MEMORY;
+  }
+  catch (const std::exception& e) {
+    (h ? h->last_error : g_create_error) = e.what();
+    return GGNN_DEVICE_ERROR;
+  }
+}
+
+#define GGNN_NEED_HANDLE(h) \
+  if (!(h))                 \
+  return GGNN_INVALID_ARGUMENT
+}  // namespace
+
+extern "C" {
+
+const char* ggnn_version(void)
+{
+  return "ggnn_amd 0.1.0 (gfx950)";
+}
+
+ggnn_status ggnn_create(ggnn_t** out)
+{
+  if (!out)
+    return GGNN_INVALID_ARGUMENT;
+  return guarded(nullptr, [&] { *out = new ggnn_handle(); });
+}
+
+void ggnn_destroy(ggnn_t* h)
+{
+  delete h;
+}
+
+const char* ggnn_last_error(const ggnn_t* h)
+{
+  return h ? h->last_error.c_str() : g_create_error.c_str();
+}
+
+void ggnn_set_log_level(int level)
+{
+  g_log_level = level;
+}
+
+ggnn_status ggnn_set_working_directory(ggnn_t* h, const char* dir)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    // ggnn.cu:69-76
+    const std::filesystem::path p = dir ? dir : "";
+    h->graph_dir = p.empty() ? std::filesystem::current_path() : std::filesystem::absolute(p);
+    std::error_code ec;
+    std::filesystem::create_directories(h->graph_dir, ec);
+    GGNN_REQUIRE(!ec, GGNN_IO_ERROR, "cannot create working directory " + h->graph_dir.string());
+  });
+}
+
+ggnn_status ggnn_set_cpu_memory_limit(ggnn_t* h, size_t memory_limit)
+{
+  GGNN_NEED_HANDLE(h);
+  h->cpu_memory_limit = memory_limit;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_reserved_gpu_memory(ggnn_t* h, size_t reserved_memory)
+{
+  GGNN_NEED_HANDLE(h);
+  h->reserved_gpu_memory = reserved_memory;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_gpus(ggnn_t* h, const int* gpu_ids, size_t num_gpus)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    int count = 0;
+    (void)hipGetDeviceCount(&count);
+    for (size_t i = 0; i < num_gpus; ++i) {
+      // ggnn.cu:94-97 (accepts gpu_id == device count, quirk Q5)
+      GGNN_REQUIRE(gpu_ids[i] >= 0 && gpu_ids[i] <= count, GGNN_OUT_OF_RANGE,
+                   "Invalid GPU index " + std::to_string(gpu_ids[i]) + " given.");
+    }
+    h->gpu_ids.assign(gpu_ids, gpu_ids + num_gpus);
+  });
+}
+
+ggnn_status ggnn_set_shard_size(ggnn_t* h, uint32_t n_shard)
+{
+  GGNN_NEED_HANDLE(h);
+  h->N_shard = n_shard;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_return_results_on_gpu(ggnn_t* h, int v)
+{
+  GGNN_NEED_HANDLE(h);
+  h->return_results_on_gpu = v != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable)
+{
+  GGNN_NEED_HANDLE(h);
+  h->collect_counters = enable != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_base(ggnn_t* h, const void* data, uint64_t N, uint32_t D, ggnn_dtype dtype,
+                          ggnn_location location, int gpu_id, int take_copy)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    // ggnn.cu:146-152
+    GGNN_REQUIRE(!h->prepared, GGNN_INVALID_STATE,
+                 "The base cannot be changed once the GPU instances are setup.");
+    GGNN_REQUIRE(dtype == GGNN_F32 || dtype == GGNN_U8, GGNN_INVALID_ARGUMENT,
+                 "unsupported datatype for base");
+    // ggnn.cu:466-487: the element type is fixed by the first set_base
+    GGNN_REQUIRE(!h->base_set || h->base_dtype == dtype, GGNN_INVALID_ARGUMENT,
+                 "base has already been set with a different data type");
+    GGNN_REQUIRE(data != nullptr && N > 0 && D > 0, GGNN_INVALID_ARGUMENT, "empty base");
+    const size_t bytes = N * D * dtype_size(dtype);
+    h->base_host_copy.clear();
+    h->base_dev_copy.release();
+    h->d_base = nullptr;
+    h->base_src = data;
+    h->base_loc = location;
+    h->base_gpu = gpu_id;
+    if (take_copy) {
+      if (location == GGNN_CPU) {
+        h->base_host_copy.assign(static_cast<const uint8_t*>(data),
+                                 static_cast<const uint8_t*>(data) + bytes);
+        h->base_src = h->base_host_copy.data();
+      }
+      else {
+        GGNN_HIP_CHECK(hipSetDevice(gpu_id));
+        h->base_dev_copy.alloc(bytes);
+        GGNN_HIP_CHECK(hipMemcpy(h->base_dev_copy.p, data, bytes, hipMemcpyDeviceToDevice));
+        h->base_src = h->base_dev_copy.p;
+      }
+    }
+    h->base_N = N;
+    h->base_D = D;
+    h->base_dtype = dtype;
+    h->base_set = true;
+  });
+}
+
+ggnn_status ggnn_build(ggnn_t* h, uint32_t k_build, float tau_build,
+                       uint32_t refinement_iterations, ggnn_measure measure)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] { h->build(k_build, tau_build, refinement_iterations, measure); });
+}
+
+ggnn_status ggnn_store(ggnn_t* h)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] { h->store(); });
+}
+
+ggnn_status ggnn_load(ggnn_t* h, uint32_t k_build)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] { h->load(k_build); });
+}
+
+ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
+                       ggnn_location location, int /*gpu_id*/, uint32_t k_query, float tau_query,
+                       uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
+                       float* dists_out, ggnn_location out_location)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    h->query(query, Nq, D, dtype, location, k_query, tau_query, max_iterations, measure, ids_out,
+             dists_out, out_location);
+  });
+}
+
+ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
+                          ggnn_dtype dtype, ggnn_location location, int /*gpu_id*/,
+                          uint32_t k_gt, ggnn_measure measure, int32_t* ids_out, float* dists_out,
+                          ggnn_location out_location)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    h->bf_query(query, Nq, D, dtype, location, k_gt, measure, ids_out, dists_out, out_location);
+  });
+}
+
+ggnn_status ggnn_get_graph(ggnn_t* h, uint32_t global_shard_id, ggnn_graph_view* out)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    GGNN_REQUIRE(out != nullptr, GGNN_INVALID_ARGUMENT, "null output");
+    // ggnn.cu:392-413
+    GGNN_REQUIRE(h->prepared && !h->shards.empty() && h->shards[0].ready, GGNN_INVALID_STATE,
+                 "No graph has been built or loaded yet.");
+    GGNN_REQUIRE(global_shard_id < h->num_shards, GGNN_INVALID_STATE,
+                 "Shard " + std::to_string(global_shard_id) + " does not exist.");
+    const Shard& sh = h->shards[global_shard_id];
+    out->config = h->cfg;
+    out->graph = sh.graph;
+    out->translation = sh.translation;
+    out->selection = sh.selection;
+    out->nn1_stats = sh.nn1_stats;
+    out->gpu_id = h->device;
+  });
+}
+
+ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_ms, float* bf_ms)
+{
+  GGNN_NEED_HANDLE(h);
+  if (build_ms)
+    *build_ms = h->build_ms;
+  if (query_ms)
+    *query_ms = h->query_ms;
+  if (bf_ms)
+    *bf_ms = h->bf_ms;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop)
+{
+  GGNN_NEED_HANDLE(h);
+  if (n_dist)
+    *n_dist = h->last_n_dist;
+  if (n_pop)
+    *n_pop = h->last_n_pop;
+  return GGNN_OK;
+}
+
+// ---- Section 2: operator seam ----------------------------------------------------------------
+
+ggnn_status ggnn_graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild,
+                                   ggnn_graph_config* out)
+{
+  return guarded(nullptr, [&] { graph_config_init(N, D, KBuild, out); });
+}
+
+ggnn_status ggnn_query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations,
+                              uint32_t* cache_size, uint32_t* sorted_size)
+{
+  return guarded(nullptr, [&] { query_sizing(D, k_query, max_iterations, cache_size, sorted_size); });
+}
+
+ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
+                          const void* query, uint32_t Nq, const int32_t* graph0,
+                          uint32_t KBuild, const int32_t* start, uint32_t num_start,
+                          const float* nn1_stats, uint32_t k_query, float tau_query,
+                          uint32_t max_iterations, ggnn_measure measure,
+                          uint32_t shards_per_gpu, uint32_t on_gpu_shard, int32_t* ids,
+                          float* dists, uint32_t* n_dist, uint32_t* n_pop, void* stream)
+{
+  return guarded(nullptr, [&] {
+    QueryLaunch q{base,      query,          dtype,         N_base,       D,       Nq,
+                  graph0,    KBuild,         start,         num_start,    nn1_stats, k_query,
+                  tau_query, max_iterations, measure,       shards_per_gpu, on_gpu_shard, ids,
+                  dists,     n_dist,         n_pop};
+    launch_query(q, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
+                             const void* query, uint32_t Nq, uint32_t k_query,
+                             ggnn_measure measure, int32_t* ids, float* dists, void* stream)
+{
+  return guarded(nullptr, [&] {
+    BfLaunch b{base, query, dtype, N_base, D, Nq, k_query, measure, ids, dists};
+    launch_bf_query(b, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_top(const void* base, ggnn_dtype dtype, uint32_t D, ggnn_measure measure,
+                        uint32_t KBuild, const int32_t* translation_layer, uint32_t N_layer,
+                        uint32_t S, uint32_t S_offset, uint32_t layer, int32_t* graph_layer,
+                        float* nn1_dist_buffer, void* stream)
+{
+  return guarded(nullptr, [&] {
+    TopLaunch t{base, dtype, D, measure, KBuild, translation_layer, N_layer, S, S_offset, layer,
+                graph_layer, nn1_dist_buffer};
+    launch_top(t, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_merge(const void* base, ggnn_dtype dtype, ggnn_measure measure,
+                          const ggnn_graph_config* cfg, const int32_t* graph_all,
+                          const int32_t* translation_all, const int32_t* selection_all,
+                          const float* nn1_stats, float tau_build, uint32_t layer_top,
+                          uint32_t layer_btm, int32_t* graph_buffer, float* nn1_dist_buffer,
+                          uint32_t* n_dist, void* stream)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(cfg != nullptr, GGNN_INVALID_ARGUMENT, "null graph config");
+    MergeLaunch m{base,      dtype,     measure,   *cfg,         graph_all,       translation_all,
+                  selection_all, nn1_stats, tau_build, layer_top, layer_btm,      graph_buffer,
+                  nn1_dist_buffer, n_dist};
+    launch_merge(m, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_select(const ggnn_graph_config* cfg, uint32_t layer,
+                           const float* nn1_dist_buffer, const float* rng,
+                           int32_t* translation_all, int32_t* selection_all, void* stream)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(cfg != nullptr, GGNN_INVALID_ARGUMENT, "null graph config");
+    launch_select(*cfg, layer, nn1_dist_buffer, rng, translation_all, selection_all,
+                  static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id,
+                            void* stream)
+{
+  return guarded(nullptr,
+                 [&] { launch_uniform(out, n, seed, stream_id, static_cast<hipStream_t>(stream)); });
+}
+
+ggnn_status ggnn_op_sym(const void* base, ggnn_dtype dtype, ggnn_measure measure, uint32_t D,
+                        uint32_t KBuild, const int32_t* graph_layer,
+                        const int32_t* translation_layer, uint32_t N_layer,
+                        const float* nn1_stats, float tau_build, int32_t* sym_buffer,
+                        uint32_t* sym_atomic, uint32_t first_n, uint32_t count, void* stream)
+{
+  return guarded(nullptr, [&] {
+    SymLaunch s{base,      dtype,     measure,    D,          KBuild,  graph_layer, translation_layer,
+                N_layer,   nn1_stats, tau_build,  sym_buffer, sym_atomic, first_n,  count};
+    launch_sym(s, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buffer,
+                                     const uint32_t* sym_atomic, int32_t* graph_layer,
+                                     void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_sym_buffer_merge(KBuild, N_layer, sym_buffer, sym_atomic, graph_layer,
+                            static_cast<hipStream_t>(stream));
+  });
+}
+
+size_t ggnn_nn1_stats_scratch_floats(void)
+{
+  return 2 * kStatsBlocks;
+}
+
+ggnn_status ggnn_op_nn1_stats(const float* nn1_dist_buffer, uint32_t N, float* scratch,
+                              float* out, void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_nn1_stats(nn1_dist_buffer, N, scratch, out, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, float* dists,
+                                       void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_sort_shard_results(Nq, row_len, ids, dists, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                  uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                  const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                  void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_merge_results(Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists,
+                         ids_out, dists_out, static_cast<hipStream_t>(stream));
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// merge kernel: hierarchical search from the top segment down to layer_btm for every point of
+// layer_btm; one wave64 per point.
+// Reference: MergeKernel::operator() and get_top_seg_offset, src/ggnn/construction/merge_layer.cu
+// :40-158; sizing include/ggnn/construction/merge_layer.cuh:40-65.
+#include "traversal.hpp"
+
+namespace ggnn_amd {
+
+struct MergeArgs {
+  const void* base;
+  const int32_t* graph_all;
+  const int32_t* translation_all;
+  const int32_t* selection_all;
+  const float* nn1_stats;
+  int32_t* graph_buffer;
+  float* nn1_dist_buffer;
+  uint32_t* n_dist;
+  uint32_t D, KBuild, S, G, S0, S0_off, layer_top, layer_btm, sorted, N_btm;
+  uint32_t Ns_off[kLayers], STs_off[kLayers];
+  float tau;
+};
+
+constexpr uint32_t kMergeCache = 256;      // merge_layer.cuh:44
+constexpr uint32_t kMergeIterations = 200; // merge_layer.cuh:43
+
+uint32_t merge_sorted_size(uint32_t KBuild)
+{
+  // merge_layer.cuh:68-69 (CACHE_SIZE = 256 < 512)
+  return std::max(64u, next_multiple32(KBuild + 1 + 16));
+}
+
+template <typename BaseT, int LPR, int NCH, int R, int MODE>
+__global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const WaveLds lds(lds_raw, kMergeCache);
+  const int lane = threadIdx.x;
+  const uint32_t un = blockIdx.x;
+  const int n = static_cast<int>(un);
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const uint32_t K = a.KBuild;
+
+  // merge_layer.cu:74-76 (xi from the MEAN nn1 distance, quirk Q4)
+  const float nn1 = a.nn1_stats[0];
+  const float xi = (MODE == kL2) ? (nn1 * nn1) * a.tau * a.tau : nn1 * a.tau;
+
+  const int m = (!a.layer_btm) ? n : a.translation_all[a.STs_off[a.layer_btm] + un];
+
+  DistEngine<BaseT, LPR, NCH> de;
+  de.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D);
+
+  SortedList<R> sl;
+  sl.init(K + 1, a.sorted, kMergeCache, xi, lds.known);
+  uint32_t cnt_dist = 0;
+
+  {
+    // get_top_seg_offset, merge_layer.cu:40-61
+    uint32_t seg_btm = un / a.S;
+    if (!a.layer_btm) {
+      const uint32_t offset_points = a.S0_off * (a.S0 + 1);
+      seg_btm = (un < offset_points) ? un / (a.S0 + 1) : a.S0_off + (un - offset_points) / a.S0;
+    }
+    uint32_t powG = a.G;
+    for (uint32_t i = 1; i < a.layer_top - a.layer_btm; ++i)
+      powG *= a.G;
+    const uint32_t s_offset = (seg_btm / powG) * a.S;
+    // fetch starting points, merge_layer.cu:86-94
+    for (uint32_t i = 0; i < a.S; i += kKBlock) {
+      const int cand = (lane < (int)kKBlock && i + lane < a.S)
+                           ? static_cast<int>(s_offset + i + lane)
+                           : kEmptyKey;
+      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, a.translation_all + a.STs_off[a.layer_top]);
+    }
+  }
+
+  // hierarchic kNN search, merge_layer.cu:97-119
+  for (uint32_t layer = a.layer_top - 1; layer >= a.layer_btm && layer != 0xffffffffu; --layer) {
+    sl.transform(a.selection_all + a.STs_off[layer + 1], lds.known,
+                 reinterpret_cast<float*>(lds.known + a.sorted));
+    const int32_t* tr = (!layer) ? nullptr : a.translation_all + a.STs_off[layer];
+    if (layer == a.layer_btm) {
+      const int cand = (lane == 0) ? n : kEmptyKey;
+      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, tr);
+    }
+    for (uint32_t ite = 0; ite < kMergeIterations; ++ite) {
+      const int anchor = sl.pop(sl.criteria(), lds.known);
+      if (anchor == kEmptyKey)
+        break;
+      const int32_t* row =
+          a.graph_all + (static_cast<size_t>(a.Ns_off[layer]) + static_cast<uint32_t>(anchor)) * K;
+      for (uint32_t j = 0; j < K; j += kKBlock) {
+        const int cand = (lane < (int)kKBlock && j + lane < K) ? row[j + lane] : kEmptyKey;
+        cnt_dist += fetch<MODE, true>(sl, de, lds, cand, tr);
+      }
+    }
+  }
+
+  // own index among the first K entries (merge_layer.cu:121-134); keys of the best list are unique
+  int own = -1;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = r * kWave + lane;
+    const unsigned long long mm = __ballot(i < K && sl.key[r] == n);
+    if (mm)
+      own = r * kWave + __ffsll(static_cast<long long>(mm)) - 1;
+  }
+  // write K neighbours skipping self (Q3: own == -1 drops entry 0), merge_layer.cu:135-145
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = r * kWave + lane;
+    int nk = __shfl_down(sl.key[r], 1);
+    if (r + 1 < R) {
+      const int bk = rdlane(sl.key[r + 1], 0);
+      if (lane == 63)
+        nk = bk;
+    }
+    if (i < (int)K) {
+      const int idx = (i >= own) ? nk : sl.key[r];
+      a.graph_buffer[static_cast<size_t>(un) * K + i] = (idx != kEmptyKey) ? idx : n;
+    }
+  }
+  // nn1 = first non-zero distance after self, merge_layer.cu:147-157
+  if (!a.layer_btm) {
+    int i = own + 1;
+    float dist;
+    do {
+      dist = sl.dist_at(i);
+      ++i;
+    } while (dist == 0.0f && i < sl.BEST);
+    if (MODE == kL2)
+      dist = sqrtf(dist);
+    if (lane == 0)
+      a.nn1_dist_buffer[un] = dist;
+  }
+  if (lane == 0 && a.n_dist)
+    a.n_dist[un] = cnt_dist;
+}
+
+template <typename BaseT, int LPR, int NCH, int MODE>
+static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
+{
+  const size_t lds = wave_lds_bytes(kMergeCache);
+  if (args.sorted <= 64)
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.N_btm), dim3(kWave),
+                       lds, stream, args);
+  else if (args.sorted <= 128)
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.N_btm), dim3(kWave),
+                       lds, stream, args);
+  else
+    throw Error(GGNN_UNSUPPORTED,
+                "this build keeps the sorted cache in registers and supports KBuild <= 111");
+}
+
+void launch_merge(const MergeLaunch& a, hipStream_t stream)
+{
+  const ggnn_graph_config& c = a.cfg;
+  GGNN_REQUIRE(a.layer_top > a.layer_btm && a.layer_top < kLayers, GGNN_INVALID_ARGUMENT,
+               "merge needs layer_top > layer_btm");
+  check_vector_layout(a.base, c.D, a.dtype);
+  MergeArgs args{};
+  args.base = a.base;
+  args.graph_all = a.graph_all;
+  args.translation_all = a.translation_all;
+  args.selection_all = a.selection_all;
+  args.nn1_stats = a.nn1_stats;
+  args.graph_buffer = a.graph_buffer;
+  args.nn1_dist_buffer = a.nn1_dist_buffer;
+  args.n_dist = a.n_dist;
+  args.D = c.D;
+  args.KBuild = c.KBuild;
+  args.S = c.S;
+  args.G = c.G;
+  args.S0 = c.S0;
+  args.S0_off = c.S0_off;
+  args.layer_top = a.layer_top;
+  args.layer_btm = a.layer_btm;
+  args.sorted = merge_sorted_size(c.KBuild);
+  args.N_btm = c.Ns[a.layer_btm];
+  for (uint32_t l = 0; l < kLayers; ++l) {
+    args.Ns_off[l] = c.Ns_offsets[l];
+    args.STs_off[l] = c.STs_offsets[l];
+  }
+  args.tau = a.tau_build;
+  GGNN_REQUIRE(args.sorted < kMergeCache, GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
+  if (!args.N_btm)
+    return;
+
+#define GGNN_LAUNCH_MERGE(T, LPR, NCH)                     \
+  do {                                                     \
+    if (a.measure == GGNN_EUCLIDEAN)                       \
+      launch_merge_r<T, LPR, NCH, kL2>(args, stream);      \
+    else                                                   \
+      launch_merge_r<T, LPR, NCH, kCos>(args, stream);     \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, c.D, GGNN_LAUNCH_MERGE);
+#undef GGNN_LAUNCH_MERGE
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ggnn_amd

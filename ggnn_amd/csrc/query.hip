@@ -1,0 +1,158 @@
+// query kernel: best-first graph traversal, one wave64 per query.
+// Reference: QueryKernel::operator(), src/ggnn/query/query_layer.cu:39-97; host sizing
+// QueryKernelsImpl::query, src/ggnn/query/query_kernels.cu:50-186.
+#include "traversal.hpp"
+
+namespace ggnn_amd {
+
+struct QueryArgs {
+  const void* base;
+  const void* query;
+  const int32_t* graph0;
+  const int32_t* start;
+  const float* nn1_stats;
+  int32_t* ids;
+  float* dists;
+  uint32_t* n_dist;
+  uint32_t* n_pop;
+  uint32_t D, Nq, N_base, KBuild, num_start, KQuery, sorted, cache, max_iters;
+  uint32_t shards_per_gpu, on_gpu_shard;
+  float tau;
+};
+
+template <typename BaseT, int LPR, int NCH, int R, int MODE>
+__global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const WaveLds lds(lds_raw, a.cache);
+  const int lane = threadIdx.x;
+  const uint32_t n = blockIdx.x;
+
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const BaseT* query = static_cast<const BaseT*>(a.query);
+
+  // query_layer.cu:48-50 (xi from the MAX nn1 distance, quirk Q4)
+  const float nn1 = a.nn1_stats[1];
+  const float xi = (MODE == kL2) ? (nn1 * nn1) * a.tau * a.tau : nn1 * a.tau;
+
+  DistEngine<BaseT, LPR, NCH> de;
+  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+
+  SortedList<R> sl;
+  sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known);
+
+  uint32_t cnt_dist = 0, cnt_pop = 0;
+
+  // fetch_unfiltered(d_starting_points, nullptr, S), query_layer.cu:54-55
+  for (uint32_t i = 0; i < a.num_start; i += kKBlock) {
+    const int cand = (lane < (int)kKBlock && i + lane < a.num_start) ? a.start[i + lane]
+                                                                      : kEmptyKey;
+    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr);
+  }
+
+  for (uint32_t ite = 0; ite < a.max_iters; ++ite) {
+    // query_layer.cu:58-63
+    const float d0 = sl.dist_at(0);
+    sl.xi = (MODE == kL2) ? fminf(xi, d0 * a.tau * a.tau) : fminf(xi, d0 * a.tau);
+    const int anchor = sl.pop(sl.criteria(), lds.known);
+    if (anchor == kEmptyKey)
+      break;
+    ++cnt_pop;
+    // query_layer.cu:69-77
+    const int32_t* row = a.graph0 + static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild;
+    for (uint32_t i = 0; i < a.KBuild; i += kKBlock) {
+      const int cand = (lane < (int)kKBlock && i + lane < a.KBuild) ? row[i + lane] : kEmptyKey;
+      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr);
+    }
+  }
+
+  // write_best + dists, query_layer.cu:81-90 (EMPTY becomes -1 + offset, as in the reference)
+  const size_t out_row = (static_cast<size_t>(n) * a.shards_per_gpu + a.on_gpu_shard) * a.KQuery;
+  const int32_t id_offset = static_cast<int32_t>(a.on_gpu_shard * a.N_base);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = r * kWave + lane;
+    if (i < a.KQuery) {
+      a.ids[out_row + i] = sl.key[r] + id_offset;
+      a.dists[out_row + i] = sl.dist[r];
+    }
+  }
+  if (lane == 0) {
+    if (a.n_dist)
+      a.n_dist[n] = cnt_dist;
+    if (a.n_pop)
+      a.n_pop[n] = cnt_pop;
+  }
+}
+
+void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_t* cache_size,
+                  uint32_t* sorted_size)
+{
+  // query_kernels.cu:55-110
+  GGNN_REQUIRE(k_query >= 1 && k_query <= 6000, GGNN_INVALID_ARGUMENT, "KQuery must be in [1, 6000]");
+  GGNN_REQUIRE(max_iterations <= 8192, GGNN_INVALID_ARGUMENT, "max_iterations must be <= 8192");
+  GGNN_REQUIRE(D >= 1 && D <= 4096, GGNN_INVALID_ARGUMENT, "D must be in [1, 4096]");
+  const uint32_t required_sorted = next_multiple32(k_query + 1 + 16);
+  const uint32_t cache =
+      std::max(std::max(256u, required_sorted + 32u), bit_ceil_u32(max_iterations));
+  GGNN_REQUIRE(cache <= 8192, GGNN_INVALID_ARGUMENT, "cache size exceeds 8192");
+  *cache_size = cache;
+  *sorted_size = std::max(cache < 512u ? 64u : 32u, required_sorted);
+}
+
+template <typename BaseT, int LPR, int NCH, int MODE>
+static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
+{
+  const size_t lds = wave_lds_bytes(args.cache);
+  if (sorted <= 64)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.Nq), dim3(kWave), lds,
+                       stream, args);
+  else if (sorted <= 128)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.Nq), dim3(kWave), lds,
+                       stream, args);
+  else
+    throw Error(GGNN_UNSUPPORTED,
+                "this build keeps the sorted cache in registers and supports KQuery <= 111");
+}
+
+void launch_query(const QueryLaunch& a, hipStream_t stream)
+{
+  if (a.Nq == 0)
+    return;
+  check_vector_layout(a.base, a.D, a.dtype);
+  check_vector_layout(a.query, a.D, a.dtype);
+  QueryArgs args{};
+  args.base = a.base;
+  args.query = a.query;
+  args.graph0 = a.graph0;
+  args.start = a.start;
+  args.nn1_stats = a.nn1_stats;
+  args.ids = a.ids;
+  args.dists = a.dists;
+  args.n_dist = a.n_dist;
+  args.n_pop = a.n_pop;
+  args.D = a.D;
+  args.Nq = a.Nq;
+  args.N_base = a.N_base;
+  args.KBuild = a.KBuild;
+  args.num_start = a.num_start;
+  args.KQuery = a.k_query;
+  query_sizing(a.D, a.k_query, a.max_iterations, &args.cache, &args.sorted);
+  args.max_iters = a.max_iterations;
+  args.shards_per_gpu = a.shards_per_gpu;
+  args.on_gpu_shard = a.on_gpu_shard;
+  args.tau = a.tau_query;
+
+#define GGNN_LAUNCH_QUERY(T, LPR, NCH)                                   \
+  do {                                                                   \
+    if (a.measure == GGNN_EUCLIDEAN)                                     \
+      launch_query_r<T, LPR, NCH, kL2>(args, args.sorted, stream);       \
+    else                                                                 \
+      launch_query_r<T, LPR, NCH, kCos>(args, args.sorted, stream);      \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_QUERY);
+#undef GGNN_LAUNCH_QUERY
+  GGNN_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ggnn_amd

@@ -1,0 +1,575 @@
+// Wave64 device primitives of the GGNN traversal (query / merge / sym kernels), gfx950.
+//
+// Design: ONE WAVE PER SEARCH.  The reference keeps a per-block cache in shared
+// memory and pays >= 3 block barriers plus a SORTED-wide LDS scan per accepted candidate
+// (include/ggnn/cuda_utils/simple_knn_cache.cuh:126-213).  Here the sorted part of that cache
+// (best list + priority-queue ring) lives in registers, one entry per lane in LOGICAL order, so
+// push/pop are a ballot + one cross-lane shift; only the visited ring stays in LDS.  The state
+// evolution is identical to the reference's (including the ring-wrap quirk Q1 and the tie
+// rules Q2); this is validated on the CPU by oracle/wave_model.hpp against the literal
+// emulation, and on the GPU against the oracle.
+//
+// Distances are computed for all surviving candidates of a fetch at once (LPR lanes per base
+// row, 64/LPR rows per wave-wide 16-byte load instruction, i.e. fully coalesced 16 B/lane
+// gathers), then the accept/push sequence is replayed in candidate order, which is what the
+// reference does one candidate at a time (simple_knn_cache.cuh:268-286).
+#pragma once
+#include "common.hpp"
+
+namespace ggnn_amd {
+
+#define GGNN_DEV __device__ __forceinline__
+
+GGNN_DEV int rdlane(int v, int l)
+{
+  return __builtin_amdgcn_readlane(v, l);
+}
+GGNN_DEV float rdlanef(float v, int l)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+GGNN_DEV int uni(int v)
+{
+  return __builtin_amdgcn_readfirstlane(v);
+}
+GGNN_DEV float inf_f()
+{
+  return __builtin_huge_valf();
+}
+
+template <int CTRL>
+GGNN_DEV float dpp_f(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// sum over groups of LPR consecutive lanes; every lane of a group receives the group total
+template <int LPR>
+GGNN_DEV float group_sum(float v)
+{
+  v += dpp_f<0xB1>(v);  // quad_perm:[1,0,3,2]
+  v += dpp_f<0x4E>(v);  // quad_perm:[2,3,0,1]
+  if (LPR >= 8)
+    v += dpp_f<0x141>(v);  // row_half_mirror
+  if (LPR >= 16)
+    v += dpp_f<0x140>(v);  // row_mirror
+  if (LPR >= 32)
+    v += __shfl_xor(v, 16);
+  if (LPR >= 64)
+    v += __shfl_xor(v, 32);
+  return v;
+}
+
+// LDS layout of one wave (ints): known[CACHE] | ckeys[32] | cd0[32] | cd1[32]
+//   known[0,SORTED)        copy of the sorted keys, refreshed at every filtered fetch
+//   known[SORTED,CACHE)    visited ring (reference: s_cache[SORTED_SIZE..CACHE_SIZE))
+struct WaveLds {
+  int* known;
+  int* ckeys;
+  float* cd0;
+  float* cd1;
+  GGNN_DEV WaveLds(int* base, int cache)
+      : known(base), ckeys(base + cache), cd0(reinterpret_cast<float*>(base + cache + 32)),
+        cd1(reinterpret_cast<float*>(base + cache + 64))
+  {
+  }
+  static constexpr size_t extra_ints = 96;
+};
+inline size_t wave_lds_bytes(uint32_t cache)
+{
+  return (cache + WaveLds::extra_ints) * sizeof(int);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sorted part of the cache: logical entry i = r*64 + lane.
+//   [0,BEST) best list, [BEST,SORTED) priority queue in logical order (head first).
+// Reference: SimpleKNNCache, simple_knn_cache.cuh:58-352.  TIES_AFTER selects the KBestList
+// tie rule (k_best_list.cuh:92-103) instead of the cache's (Q2).
+// ---------------------------------------------------------------------------------------------
+template <int R>
+struct SortedList {
+  int key[R];
+  float dist[R];
+  int BEST, SORTED, P, VIS;
+  int head_in;    // r_prioQ_head - BEST
+  int vis_head;   // r0_visited_head - SORTED
+  int vis_count;  // valid entries of the visited ring
+  float xi;
+
+  GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* known)
+  {
+    BEST = best;
+    SORTED = sorted;
+    P = sorted - best;
+    VIS = cache - sorted;
+    xi = xi_;
+    reset(known);
+  }
+  // simple_knn_cache.cuh:73-87
+  GGNN_DEV void reset(int* known)
+  {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      key[r] = kEmptyKey;
+      dist[r] = inf_f();
+    }
+    head_in = 0;
+    vis_head = 0;
+    vis_count = 0;
+    for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
+      known[i] = kEmptyKey;
+  }
+
+  GGNN_DEV float dist_at(int i) const
+  {
+    if constexpr (R == 1)
+      return rdlanef(dist[0], i);
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((i >> 6) == r)
+        v = rdlanef(dist[r], i & 63);
+    return v;
+  }
+  GGNN_DEV int key_at(int i) const
+  {
+    if constexpr (R == 1)
+      return rdlane(key[0], i);
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((i >> 6) == r)
+        v = rdlane(key[r], i & 63);
+    return v;
+  }
+  // simple_knn_cache.cuh:121-124
+  GGNN_DEV float criteria() const
+  {
+    return dist_at(BEST - 1) + xi;
+  }
+
+  // simple_knn_cache.cuh:126-213 in lane form (oracle/wave_model.hpp::push)
+  GGNN_DEV void push(int k, float d)
+  {
+    bool dup = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      dup |= (key[r] == k);
+    if (__any(dup))
+      return;
+    // logical index of the entry in physical slot BEST; Q1: nothing shifts into it
+    const int qlane = head_in ? BEST + (P - head_in) : -1;
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+      const int i = r * kWave + lane;
+      int pk = __shfl_up(key[r], 1);
+      float pd = __shfl_up(dist[r], 1);
+      if (r > 0) {
+        const int bk = rdlane(key[r - 1], 63);
+        const float bd = rdlanef(dist[r - 1], 63);
+        if (lane == 0) {
+          pk = bk;
+          pd = bd;
+        }
+      }
+      const bool first = (i == 0) || (i == BEST);
+      const bool active = (dist[r] >= d) && (i < SORTED);
+      const bool prev_active = !first && (pd >= d);
+      if (active) {
+        if (first || !prev_active) {
+          key[r] = k;
+          dist[r] = d;
+        }
+        else if (i != qlane && pk != kEmptyKey) {
+          key[r] = pk;
+          dist[r] = pd;
+        }
+      }
+    }
+  }
+
+  // KBestList::add_unique, k_best_list.cuh:77-109 (stable insert after equal distances, no
+  // duplicate check); only the best list is used (BEST == SORTED).
+  GGNN_DEV void push_best_stable(int k, float d)
+  {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+      const int i = r * kWave + lane;
+      int pk = __shfl_up(key[r], 1);
+      float pd = __shfl_up(dist[r], 1);
+      if (r > 0) {
+        const int bk = rdlane(key[r - 1], 63);
+        const float bd = rdlanef(dist[r - 1], 63);
+        if (lane == 0) {
+          pk = bk;
+          pd = bd;
+        }
+      }
+      const bool active = (d < dist[r]) && (i < BEST);
+      const bool prev_active = (i != 0) && (d < pd);
+      if (active) {
+        if (!prev_active) {
+          key[r] = k;
+          dist[r] = d;
+        }
+        else {
+          key[r] = pk;
+          dist[r] = pd;
+        }
+      }
+    }
+  }
+
+  // simple_knn_cache.cuh:215-239 ; crit is criteria() (or criteria_sym() for the sym cache)
+  GGNN_DEV int pop(float crit, int* known)
+  {
+    const int k0 = key_at(BEST);
+    const float d0 = dist_at(BEST);
+    if (k0 == kEmptyKey || d0 >= crit)
+      return kEmptyKey;
+    if (threadIdx.x == 0)
+      known[SORTED + vis_head] = k0;
+    vis_head = (vis_head + 1 >= VIS) ? 0 : vis_head + 1;
+    vis_count = (vis_count + 1 > VIS) ? VIS : vis_count + 1;
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = r * kWave + lane;
+      int nk = __shfl_down(key[r], 1);
+      float nd = __shfl_down(dist[r], 1);
+      if (r + 1 < R) {
+        const int bk = rdlane(key[r + 1], 0);
+        const float bd = rdlanef(dist[r + 1], 0);
+        if (lane == 63) {
+          nk = bk;
+          nd = bd;
+        }
+      }
+      if (i >= BEST && i < SORTED) {
+        const bool last = (i == SORTED - 1);
+        key[r] = last ? kEmptyKey : nk;
+        dist[r] = last ? inf_f() : nd;
+      }
+    }
+    head_in = (head_in + 1 >= P) ? 0 : head_in + 1;
+    return k0;
+  }
+
+  // simple_knn_cache.cuh:297-333 ; goes through LDS (known[0,SORTED)), called once per layer
+  GGNN_DEV void transform(const int32_t* selection, int* known, float* scratch_d)
+  {
+    const int lane = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = r * kWave + lane;
+      if (i < BEST) {
+        int k = key[r];
+        if (k != kEmptyKey)
+          k = selection[k];
+        key[r] = k;
+        known[i] = k;
+        scratch_d[i] = dist[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = r * kWave + lane;
+      if (i >= BEST) {
+        const bool copy = (i < 2 * BEST) && (i < SORTED);
+        key[r] = copy ? known[i - BEST] : kEmptyKey;
+        dist[r] = copy ? scratch_d[i - BEST] : inf_f();
+      }
+    }
+    __syncthreads();
+    head_in = 0;
+    vis_head = 0;
+    vis_count = 0;
+    for (int i = SORTED + lane; i < SORTED + VIS; i += kWave)
+      known[i] = kEmptyKey;
+  }
+
+  // filter part of fetch(): simple_knn_cache.cuh:246-261 / simple_knn_sym_cache.cuh:408-419.
+  // cand: lanes j and j+32 hold candidate j (or EMPTY).  Returns cand with known keys blanked.
+  GGNN_DEV int filter(int cand, int* known) const
+  {
+    const int lane = threadIdx.x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = r * kWave + lane;
+      if (i < SORTED)
+        known[i] = key[r];
+    }
+    __syncthreads();
+    const int E = SORTED + vis_count;
+    const int h = lane >> 5;
+    const int4* kp = reinterpret_cast<const int4*>(known);
+    bool found = false;
+    for (int t = 0; t * 8 < E; ++t) {
+      const int4 e = kp[t * 2 + h];
+      found |= (e.x == cand) | (e.y == cand) | (e.z == cand) | (e.w == cand);
+    }
+    const int f = found ? 1 : 0;
+    const int fo = __shfl_xor(f, 32);
+    return (f | fo) ? kEmptyKey : cand;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Distance engine.  Reference: Distance, include/ggnn/cuda_utils/distance.cuh:34-164 (squared
+// L2 / |1-cos|) and the two-point variant of simple_knn_sym_cache.cuh:143-283.
+// LPR lanes cooperate on one base row, each lane owns NCH chunks of 16 bytes.
+// ---------------------------------------------------------------------------------------------
+template <typename BaseT>
+struct ChunkOf;
+template <>
+struct ChunkOf<float> {
+  using type = float4;
+  static constexpr int EPC = 4;
+  static GGNN_DEV float get(const float4& v, int e)
+  {
+    return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+  }
+  static GGNN_DEV float4 zero()
+  {
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+template <>
+struct ChunkOf<uint8_t> {
+  using type = uint4;
+  static constexpr int EPC = 16;
+  static GGNN_DEV float get(const uint4& v, int e)
+  {
+    const uint32_t w = (e >> 2) == 0 ? v.x : (e >> 2) == 1 ? v.y : (e >> 2) == 2 ? v.z : v.w;
+    return static_cast<float>((w >> (8 * (e & 3))) & 0xffu);
+  }
+  static GGNN_DEV uint4 zero()
+  {
+    return make_uint4(0u, 0u, 0u, 0u);
+  }
+};
+
+enum DistMode { kL2 = 0, kCos = 1 };
+
+template <typename BaseT, int LPR_, int NCH_>
+struct DistEngine {
+  using Base = BaseT;
+  using Chunk = typename ChunkOf<BaseT>::type;
+  static constexpr int EPC = ChunkOf<BaseT>::EPC;
+  static constexpr int LPR = LPR_;
+  static constexpr int NCH = NCH_;
+  static constexpr int ROWS = kWave / LPR;
+
+  const BaseT* base;
+  uint32_t D;
+  int g;  // lane within the row group
+  Chunk q[NCH];
+  float q_norm;  // cosine: |q|^2
+
+  GGNN_DEV bool chunk_valid(int c) const
+  {
+    return static_cast<uint32_t>((c * LPR + g) * EPC) < D;
+  }
+  GGNN_DEV Chunk load_chunk(const BaseT* row, int c) const
+  {
+    return *reinterpret_cast<const Chunk*>(row + (c * LPR + g) * EPC);
+  }
+  GGNN_DEV const BaseT* row_ptr(int m) const
+  {
+    return base + static_cast<size_t>(static_cast<uint32_t>(m)) * D;  // 64-bit addressing
+  }
+
+  // distance.cuh:104-117
+  template <int MODE>
+  GGNN_DEV void load_query(const BaseT* base_, uint32_t D_, const BaseT* qrow)
+  {
+    base = base_;
+    D = D_;
+    g = threadIdx.x % LPR;
+    float nrm = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      q[c] = chunk_valid(c) ? load_chunk(qrow, c) : ChunkOf<BaseT>::zero();
+      if (MODE == kCos) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float v = ChunkOf<BaseT>::get(q[c], e);
+          nrm = fmaf(v, v, nrm);
+        }
+      }
+    }
+    q_norm = 0.f;
+    if (MODE == kCos)
+      q_norm = group_sum<LPR>(nrm);
+  }
+
+  // per-lane partial sums over the lane's chunks of one row
+  template <int MODE>
+  GGNN_DEV void partial(const Chunk (&v)[NCH], float& a, float& b) const
+  {
+    a = 0.f;
+    b = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float o = ChunkOf<BaseT>::get(v[c], e);
+        const float qq = ChunkOf<BaseT>::get(q[c], e);
+        if (MODE == kL2) {
+          const float diff = o - qq;
+          a = fmaf(diff, diff, a);
+        }
+        else {
+          a = fmaf(o, qq, a);
+          b = fmaf(o, o, b);
+        }
+      }
+    }
+  }
+  // distance.cuh:153-158
+  GGNN_DEV float finish_cos(float dot, float nrm) const
+  {
+    const float norm_sqr = q_norm * nrm;
+    return (norm_sqr > 0.0f) ? fabsf(1.0f - dot / sqrtf(norm_sqr)) : 1.0f;
+  }
+};
+
+// rows in flight per distance pass (register budget: STEPS*NCH chunks of 4 VGPRs)
+template <int LPR, int NCH>
+struct StepsOf {
+  static constexpr int value = (NCH <= 2) ? 4 : (NCH <= 4) ? 2 : 1;
+};
+
+// Computes the distances of the nsurv compacted candidates in lds.ckeys[0,nsurv) and leaves
+// them in lds.cd0[0,nsurv).  Out-of-range chunks are neither loaded nor accumulated.
+template <int MODE, class DE>
+GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
+                                const int32_t* translation)
+{
+  constexpr int STEPS = StepsOf<DE::LPR, DE::NCH>::value;
+  constexpr int ROWS = DE::ROWS;
+  using Chunk = typename DE::Chunk;
+  const int lane = threadIdx.x;
+  const int grp = lane / DE::LPR;
+  for (int s0 = 0; s0 < nsurv; s0 += ROWS * STEPS) {
+    Chunk v[STEPS][DE::NCH];
+    int rr[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int r = s0 + s * ROWS + grp;
+      const bool valid = r < nsurv;
+      rr[s] = valid ? r : -1;
+      int m = 0;
+      if (valid) {
+        m = lds.ckeys[r];
+        if (translation)
+          m = translation[m];
+      }
+      const auto* row = de.row_ptr(m);
+#pragma unroll
+      for (int c = 0; c < DE::NCH; ++c) {
+        v[s][c] = ChunkOf<typename DE::Base>::zero();
+        if (valid && de.chunk_valid(c))
+          v[s][c] = de.load_chunk(row, c);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      float a, b;
+      de.template partial<MODE>(v[s], a, b);
+      a = group_sum<DE::LPR>(a);
+      if (MODE == kCos)
+        b = group_sum<DE::LPR>(b);
+      if (rr[s] >= 0 && de.g == 0)
+        lds.cd0[rr[s]] = (MODE == kCos) ? de.finish_cos(a, b) : a;
+    }
+  }
+}
+
+// fetch(): simple_knn_cache.cuh:241-289.  cand: lane j (<32) holds candidate key j or EMPTY.
+// Returns the number of distance evaluations.
+template <int MODE, bool FILTER, int R, class DE>
+GGNN_DEV int fetch(SortedList<R>& sl, const DE& de, const WaveLds& lds, int cand,
+                   const int32_t* translation)
+{
+  const int lane = threadIdx.x;
+  cand = __shfl(cand, lane & 31);
+  if (FILTER)
+    cand = sl.filter(cand, lds.known);
+  const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
+  const int nsurv = __popcll(surv);
+  if (nsurv == 0)
+    return 0;
+  __syncthreads();
+  if (lane < 32 && cand != kEmptyKey)
+    lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
+  __syncthreads();
+  compute_distances<MODE>(de, lds, nsurv, translation);
+  __syncthreads();
+  const float cd = lane < nsurv ? lds.cd0[lane] : inf_f();
+  const int ck = lane < nsurv ? lds.ckeys[lane] : kEmptyKey;
+  // criteria() never increases during a fetch, so candidates failing it now fail it later
+  unsigned long long m = __ballot(cd < sl.criteria());
+  while (m) {
+    const int j = __ffsll(static_cast<long long>(m)) - 1;
+    m &= m - 1;
+    const float d = rdlanef(cd, j);
+    const int k = rdlane(ck, j);
+    if (d < sl.criteria())
+      sl.push(k, d);
+  }
+  return nsurv;
+}
+
+// block-size / chunk configuration by dimension and element type (host side)
+struct DistConfig {
+  int lpr, nch;
+};
+inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
+{
+  const uint32_t epc = dtype == GGNN_F32 ? 4 : 16;
+  const uint32_t chunks = (D + epc - 1) / epc;
+  if (chunks <= 32)
+    return {16, 2};
+  if (chunks <= 64)
+    return {16, 4};
+  if (chunks <= 256)
+    return {64, 4};
+  return {64, 16};
+}
+
+// dispatch a functor templated on <BaseT, LPR, NCH>
+#define GGNN_DISPATCH_DIST(dtype, D, F)                                           \
+  do {                                                                            \
+    const ::ggnn_amd::DistConfig _dc = ::ggnn_amd::pick_dist_config((D), (dtype)); \
+    if ((dtype) == GGNN_F32) {                                                    \
+      if (_dc.lpr == 16 && _dc.nch == 2) { F(float, 16, 2); }                     \
+      else if (_dc.lpr == 16 && _dc.nch == 4) { F(float, 16, 4); }                \
+      else if (_dc.lpr == 64 && _dc.nch == 4) { F(float, 64, 4); }                \
+      else { F(float, 64, 16); }                                                  \
+    }                                                                             \
+    else {                                                                        \
+      if (_dc.lpr == 16 && _dc.nch == 2) { F(uint8_t, 16, 2); }                   \
+      else if (_dc.lpr == 16 && _dc.nch == 4) { F(uint8_t, 16, 4); }              \
+      else if (_dc.lpr == 64 && _dc.nch == 4) { F(uint8_t, 64, 4); }              \
+      else { F(uint8_t, 64, 16); }                                                \
+    }                                                                             \
+  } while (0)
+
+inline void check_vector_layout(const void* base, uint32_t D, ggnn_dtype dtype)
+{
+  const uint32_t epc = dtype == GGNN_F32 ? 4 : 16;
+  GGNN_REQUIRE(D >= 1 && D <= 4096, GGNN_INVALID_ARGUMENT, "D must be in [1, 4096]");
+  GGNN_REQUIRE(D % epc == 0, GGNN_UNSUPPORTED,
+               "this build needs D to be a multiple of 16 bytes per row "
+               "(4 for float32, 16 for uint8)");
+  GGNN_REQUIRE((reinterpret_cast<uintptr_t>(base) & 15u) == 0, GGNN_INVALID_ARGUMENT,
+               "base/query pointers must be 16-byte aligned");
+}
+
+}  // namespace ggnn_amd

@@ -1,0 +1,222 @@
+/*
+ * ggnn_c.h -- C-ABI of the MI355X-native GGNN query+build engine (libggnn_amd.so).
+ *
+ * The reference (cgtuebingen/ggnn v0.9.1) has no C-ABI: its nanobind module wraps the C++
+ * class ggnn::GGNN<int32_t,float> directly (src/ggnn/python/nanobind.cu:184-268).  This header
+ * is the thin C boundary a binding for that class binds instead; every entry point cites the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ *  - Section 1 mirrors the public class           include/ggnn/base/ggnn.cuh:42-182
+ *  - Section 2 mirrors the internal operator seam  include/ggnn/query/query_kernels.cuh:33-61
+ *                                                  include/ggnn/construction/graph_construction.cuh:35-59
+ *    (one function per kernel, device pointers + HIP stream; used by the engine itself and by
+ *    the per-kernel parity tests with injected inputs)
+ *
+ * Conventions: plain pointers and sizes only.  Every call returns a ggnn_status; the message
+ * of the last failure is available through ggnn_last_error().  API misuse maps to the
+ * exceptions the reference throws (INVALID_STATE/INVALID_ARGUMENT -> std::runtime_error,
+ * OUT_OF_RANGE -> std::out_of_range); see INTEGRATION.md.
+ * Distances are squared L2 (no sqrt) or |1 - cos|, ids are int32, as in the reference.
+ */
+#ifndef GGNN_C_H
+#define GGNN_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GGNN_OK = 0,
+  GGNN_INVALID_ARGUMENT = 1, /* std::runtime_error / glog CHECK in the reference */
+  GGNN_INVALID_STATE = 2,    /* std::runtime_error ("base needs to be set", ...) */
+  GGNN_OUT_OF_RANGE = 3,     /* std::out_of_range (ggnn.cu:96) */
+  GGNN_OUT_OF_MEMORY = 4,
+  GGNN_DEVICE_ERROR = 5,
+  GGNN_UNSUPPORTED = 6,
+  GGNN_IO_ERROR = 7
+} ggnn_status;
+
+/* include/ggnn/base/def.h:27-30 */
+typedef enum { GGNN_EUCLIDEAN = 0, GGNN_COSINE = 1 } ggnn_measure;
+/* include/ggnn/base/dataset.cuh (DataType): base / query element type */
+typedef enum { GGNN_F32 = 0, GGNN_U8 = 1 } ggnn_dtype;
+/* include/ggnn/base/data.cuh (MemoryLocation) reduced to what the boundary needs */
+typedef enum { GGNN_CPU = 0, GGNN_GPU = 1 } ggnn_location;
+
+typedef struct ggnn_handle ggnn_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Section 1: ggnn::GGNN<int32_t,float>
+ * ---------------------------------------------------------------------------------------- */
+
+/* GGNN::GGNN() ggnn.cu:415-418 */
+ggnn_status ggnn_create(ggnn_t** out);
+void ggnn_destroy(ggnn_t* h);
+/* message of the last failed call on this handle (or of ggnn_create when h == NULL) */
+const char* ggnn_last_error(const ggnn_t* h);
+const char* ggnn_version(void);
+
+/* setWorkingDirectory ggnn.cuh:66-71 */
+ggnn_status ggnn_set_working_directory(ggnn_t* h, const char* dir);
+/* setCPUMemoryLimit ggnn.cuh:72-77 (accepted; all shards stay resident in 288 GB HBM) */
+ggnn_status ggnn_set_cpu_memory_limit(ggnn_t* h, size_t memory_limit);
+/* setReservedGPUMemory ggnn.cuh:79-84 */
+ggnn_status ggnn_set_reserved_gpu_memory(ggnn_t* h, size_t reserved_memory);
+/* setGPUs ggnn.cuh:86-98, ggnn.cu:89-100 (same range check, incl. quirk Q5) */
+ggnn_status ggnn_set_gpus(ggnn_t* h, const int* gpu_ids, size_t num_gpus);
+/* setShardSize ggnn.cuh:100-106 */
+ggnn_status ggnn_set_shard_size(ggnn_t* h, uint32_t n_shard);
+/* setReturnResultsOnGPU ggnn.cuh:108-114 */
+ggnn_status ggnn_set_return_results_on_gpu(ggnn_t* h, int return_results_on_gpu);
+
+/* setBase / setBaseReference ggnn.cuh:116-128, ggnn.cu:456-497.
+ * take_copy != 0: the engine copies the data (setBase with an owning dataset, and what the
+ * Python binding does, nanobind.cu:102-110).  take_copy == 0: borrow (setBaseReference); the
+ * caller keeps the memory alive.  Host data is staged to the device at build()/bf_query(). */
+ggnn_status ggnn_set_base(ggnn_t* h, const void* data, uint64_t N, uint32_t D, ggnn_dtype dtype,
+                          ggnn_location location, int gpu_id, int take_copy);
+
+/* build ggnn.cuh:130-137, ggnn.cu:205-240 */
+ggnn_status ggnn_build(ggnn_t* h, uint32_t k_build, float tau_build,
+                       uint32_t refinement_iterations, ggnn_measure measure);
+/* store / load ggnn.cuh:138-147, ggnn.cu:242-276 ; files <workdir>/part_<shard>.ggnn with the
+ * reference's pool layout (graph.cpp:48-91) */
+ggnn_status ggnn_store(ggnn_t* h);
+ggnn_status ggnn_load(ggnn_t* h, uint32_t k_build);
+
+/* query ggnn.cuh:149-160, ggnn.cu:518-541.
+ * ids_out/dists_out: [Nq x KQuery] (or [Nq x KQuery*shards] unmerged when results are returned
+ * on the GPU, ggnn.cuh:108-113) in memory of kind out_location. */
+ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
+                       ggnn_location location, int gpu_id, uint32_t k_query, float tau_query,
+                       uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
+                       float* dists_out, ggnn_location out_location);
+
+/* bfQuery ggnn.cuh:162-172, ggnn.cu:543-564 */
+ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
+                          ggnn_dtype dtype, ggnn_location location, int gpu_id, uint32_t k_gt,
+                          ggnn_measure measure, int32_t* ids_out, float* dists_out,
+                          ggnn_location out_location);
+
+/* layout of one graph shard, include/ggnn/base/graph_config.h:31-112 */
+typedef struct {
+  uint32_t N, D, KBuild;
+  uint32_t KF, G, S, S0, S0_off, SG, SG_off;
+  uint32_t N_all, ST_all;
+  uint32_t Bs[4], Ns[4], Ns_offsets[4], STs_offsets[4];
+} ggnn_graph_config;
+
+/* getGraph ggnn.cuh:174-175 + Graph (graph.h:38-71): device views of one shard, valid until
+ * the handle is destroyed.  graph [N_all x KBuild], translation/selection [ST_all],
+ * nn1_stats [2] = {mean, max}. */
+typedef struct {
+  ggnn_graph_config config;
+  const int32_t* graph;
+  const int32_t* translation;
+  const int32_t* selection;
+  const float* nn1_stats;
+  int gpu_id;
+} ggnn_graph_view;
+ggnn_status ggnn_get_graph(ggnn_t* h, uint32_t global_shard_id, ggnn_graph_view* out);
+
+/* tracing (reference: cudaEvent timings printed through glog, gpu_instance.cu:536-545,687-712).
+ * Sum of the HIP-event durations (ms) of the kernels of the last build / query / bf_query. */
+ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_ms, float* bf_ms);
+/* per-query work counters of the last ggnn_query (sum over queries and shards): number of
+ * distance evaluations and of successful pops; used for the roofline figure. */
+ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop);
+ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
+/* nanobind.cu:151 set_log_level */
+void ggnn_set_log_level(int level);
+
+/* ------------------------------------------------------------------------------------------
+ * Section 2: operator seam (device pointers, explicit stream).  `stream` is a hipStream_t.
+ * ---------------------------------------------------------------------------------------- */
+
+/* GraphConfig(params) src/ggnn/base/graph_config.cpp:30-113 (pure host) */
+ggnn_status ggnn_graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild,
+                                   ggnn_graph_config* out);
+/* host sizing of the query kernel, src/ggnn/query/query_kernels.cu:55-110 */
+ggnn_status ggnn_query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations,
+                              uint32_t* cache_size, uint32_t* sorted_size);
+
+/* QueryKernels::query  query_kernels.cu:50-186 -> query_layer.cu:39-97 (one shard).
+ * graph0 [N_base x KBuild], start [num_start] (= translation[L-1]), nn1_stats [2].
+ * Writes ids/dists rows (n*shards_per_gpu + on_gpu_shard) of width k_query, ids offset by
+ * on_gpu_shard*N_base.  n_dist/n_pop: optional per-query counters [Nq]. */
+ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
+                          const void* query, uint32_t Nq, const int32_t* graph0,
+                          uint32_t KBuild, const int32_t* start, uint32_t num_start,
+                          const float* nn1_stats, uint32_t k_query, float tau_query,
+                          uint32_t max_iterations, ggnn_measure measure,
+                          uint32_t shards_per_gpu, uint32_t on_gpu_shard, int32_t* ids,
+                          float* dists, uint32_t* n_dist, uint32_t* n_pop, void* stream);
+
+/* QueryKernels::bruteForceQuery  query_kernels.cu:188-264 -> bf_query_layer.cu:39-65 */
+ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
+                             const void* query, uint32_t Nq, uint32_t k_query,
+                             ggnn_measure measure, int32_t* ids, float* dists, void* stream);
+
+/* top  graph_construction.cu:201-237 -> top_merge_layer.cu:40-82.  graph_layer/translation are
+ * the views of `layer` (translation NULL on layer 0). */
+ggnn_status ggnn_op_top(const void* base, ggnn_dtype dtype, uint32_t D, ggnn_measure measure,
+                        uint32_t KBuild, const int32_t* translation_layer, uint32_t N_layer,
+                        uint32_t S, uint32_t S_offset, uint32_t layer, int32_t* graph_layer,
+                        float* nn1_dist_buffer, void* stream);
+
+/* mergeLayer  graph_construction.cu:239-296 -> merge_layer.cu:63-158 (without the final D2D
+ * copy).  graph_all [N_all x K], translation_all/selection_all [ST_all] (views "starting at
+ * layer 1", i.e. indexed with STs_offsets), writes graph_buffer [Ns[btm] x K]. */
+ggnn_status ggnn_op_merge(const void* base, ggnn_dtype dtype, ggnn_measure measure,
+                          const ggnn_graph_config* cfg, const int32_t* graph_all,
+                          const int32_t* translation_all, const int32_t* selection_all,
+                          const float* nn1_stats, float tau_build, uint32_t layer_top,
+                          uint32_t layer_btm, int32_t* graph_buffer, float* nn1_dist_buffer,
+                          uint32_t* n_dist, void* stream);
+
+/* select  graph_construction.cu:163-187 -> wrs_select_layer.cu:41-102.  rng [Ns[layer]] uniform
+ * (0,1] numbers (the reference draws them with cuRAND XORWOW; injected here). */
+ggnn_status ggnn_op_select(const ggnn_graph_config* cfg, uint32_t layer,
+                           const float* nn1_dist_buffer, const float* rng,
+                           int32_t* translation_all, int32_t* selection_all, void* stream);
+/* uniform (0,1] generator used by ggnn_build in place of curandGenerateUniform
+ * (graph_construction.cu:96-102,168-169); counter based, seed 1234 by default. */
+ggnn_status ggnn_op_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id,
+                            void* stream);
+
+/* sym  graph_construction.cu:298-379 -> sym_query_layer.cu:39-145 (blocks first_n ..
+ * first_n+count-1; sym_buffer/sym_atomic must have been cleared by the caller) */
+ggnn_status ggnn_op_sym(const void* base, ggnn_dtype dtype, ggnn_measure measure, uint32_t D,
+                        uint32_t KBuild, const int32_t* graph_layer,
+                        const int32_t* translation_layer, uint32_t N_layer,
+                        const float* nn1_stats, float tau_build, int32_t* sym_buffer,
+                        uint32_t* sym_atomic, uint32_t first_n, uint32_t count, void* stream);
+/* sym_buffer_merge  sym_buffer_merge_layer.cu:36-99 (sym_buffer is used as scratch) */
+ggnn_status ggnn_op_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buffer,
+                                     const uint32_t* sym_atomic, int32_t* graph_layer,
+                                     void* stream);
+/* computeNN1Stats + divide  graph_construction.cu:381-393,79-83 ; out = {mean, max};
+ * scratch: >= ggnn_nn1_stats_scratch_floats() floats of device memory */
+size_t ggnn_nn1_stats_scratch_floats(void);
+ggnn_status ggnn_op_nn1_stats(const float* nn1_dist_buffer, uint32_t N, float* scratch,
+                              float* out, void* stream);
+
+/* GPUInstance::sortQueryResults  gpu_instance.cu:745-790: stable ascending sort of every
+ * [row_len] row by distance (in place). */
+ggnn_status ggnn_op_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, float* dists,
+                                       void* stream);
+/* ResultMerger::merge  result_merger.cpp:51-149 on the device: `parts` = num_parts consecutive
+ * [Nq x stride] blocks (e.g. the RCCL all-gather buffer), each row sorted ascending; writes the
+ * k best per query with id + part*id_offset_per_part.  Ties: lower part first. */
+ggnn_status ggnn_op_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                  uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                  const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGNN_C_H */
