@@ -409,6 +409,8 @@ class Evaluator:
         def run_length(ref, start):
             # number of consecutive entries from `start` whose distance stays within eps
             within = (gd[:, start:] - ref[:, None]) <= eps
+            if within.shape[1] == 0:
+                return np.zeros(Nq, np.uint32)
             stop = np.where(within.all(1), within.shape[1], np.argmin(within, 1))
             return stop.astype(np.uint32)
 

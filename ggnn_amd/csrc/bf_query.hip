@@ -14,7 +14,7 @@ namespace ggnn_amd {
 struct BfArgs {
   const void* base;
   const void* query;
-  int32_t* ids;    // [Nq x slices x K] partial results (or final when slices == 1)
+  int32_t* ids;    // [slices x Nq x K] partial results (or final when slices == 1)
   float* dists;
   uint32_t D, Nq, N_base, K, slices, rows_per_slice;
 };
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
     }
   }
 
-  const size_t out = (static_cast<size_t>(n) * a.slices + slice) * a.K;
+  const size_t out = (static_cast<size_t>(slice) * a.Nq + n) * a.K;  // [slices, Nq, K]
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t i = r * kWave + lane;

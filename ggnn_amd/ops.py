@@ -37,6 +37,21 @@ def _need(t, dtype=None, name="tensor"):
     return t
 
 
+def _cfg(cfg):
+    """accept any structure with the ggnn_graph_config fields"""
+    if isinstance(cfg, GraphConfig):
+        return cfg
+    out = GraphConfig()
+    for name, _ in GraphConfig._fields_:
+        v = getattr(cfg, name)
+        if hasattr(v, "__len__"):
+            for i in range(4):
+                getattr(out, name)[i] = v[i]
+        else:
+            setattr(out, name, v)
+    return out
+
+
 def graph_config(N, D, KBuild):
     cfg = GraphConfig()
     check(lib().ggnn_graph_config_init(N, D, KBuild, cfg))
@@ -105,7 +120,7 @@ def merge(base, cfg, graph_all, translation_all, selection_all, nn1_stats, tau_b
     gb = torch.empty((Nb, cfg.KBuild), dtype=torch.int32, device=base.device)
     nn1 = torch.zeros(Nb, dtype=torch.float32, device=base.device)
     nd = torch.zeros(Nb, dtype=torch.int32, device=base.device) if counters else None
-    check(lib().ggnn_op_merge(_ptr(base), _dtype_code(base), measure, cfg, _ptr(graph_all),
+    check(lib().ggnn_op_merge(_ptr(base), _dtype_code(base), measure, _cfg(cfg), _ptr(graph_all),
                               _ptr(translation_all), _ptr(selection_all), _ptr(nn1_stats),
                               tau_build, layer_top, layer_btm, _ptr(gb), _ptr(nn1), _ptr(nd),
                               _stream()))
@@ -115,7 +130,7 @@ def merge(base, cfg, graph_all, translation_all, selection_all, nn1_stats, tau_b
 
 
 def select(cfg, layer, nn1_dist_buffer, rng, translation_all, selection_all):
-    check(lib().ggnn_op_select(cfg, layer, _ptr(nn1_dist_buffer), _ptr(rng),
+    check(lib().ggnn_op_select(_cfg(cfg), layer, _ptr(nn1_dist_buffer), _ptr(rng),
                                _ptr(translation_all), _ptr(selection_all), _stream()))
 
 

@@ -1,0 +1,156 @@
+"""CPU tests of the C-ABI boundary and the host-side mirror of the reference interface: the
+library loads, exports every symbol include/ggnn_c.h declares, host-only entry points agree
+with the oracle, and API misuse maps to the reference's exceptions.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ggnn_amd import _lib
+    return _lib.lib()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ggnn_c.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from ggnn_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in ggnn_c.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.ggnn_version()
+
+
+def test_graph_config_matches_oracle(lib, orc):
+    from ggnn_amd._lib import GraphConfig
+    for N, D, K in [(10_000, 128, 24), (1_000_000, 128, 24), (12_500_000, 96, 24),
+                    (125_000_000, 128, 24), (25_000, 128, 24), (4096, 64, 8), (77_777, 32, 40)]:
+        c = GraphConfig()
+        assert lib.ggnn_graph_config_init(N, D, K, C.byref(c)) == 0
+        assert c.as_dict() == orc.graph_config(N, D, K).as_dict()
+    c = GraphConfig()
+    assert lib.ggnn_graph_config_init(1000, 8, 1, C.byref(c)) == 1   # KBuild < 2
+    assert lib.ggnn_graph_config_init(10, 8, 24, C.byref(c)) == 1     # base too small
+
+
+def test_query_sizing_matches_oracle(lib, orc):
+    for D, K, it in [(128, 10, 200), (128, 10, 400), (960, 10, 400), (128, 100, 2000),
+                     (96, 1, 64), (128, 47, 400), (128, 48, 400)]:
+        cache, sorted_ = C.c_uint32(), C.c_uint32()
+        assert lib.ggnn_query_sizing(D, K, it, C.byref(cache), C.byref(sorted_)) == 0
+        s = orc.query_sizing(D, K, it)
+        assert (cache.value, sorted_.value) == (s.cache_size, s.sorted_size)
+    cache, sorted_ = C.c_uint32(), C.c_uint32()
+    assert lib.ggnn_query_sizing(128, 6001, 400, C.byref(cache), C.byref(sorted_)) == 1
+    assert lib.ggnn_query_sizing(128, 10, 8193, C.byref(cache), C.byref(sorted_)) == 1
+
+
+def test_error_conventions():
+    """ggnn.cu:96,150,209,282,336: misuse raises RuntimeError / IndexError like the reference."""
+    import ggnn_amd as ggnn
+    g = ggnn.GGNN()
+    with pytest.raises(RuntimeError, match="base needs to be set"):
+        g.build(24, 0.5)
+    with pytest.raises(RuntimeError, match="no graph to query"):
+        g.query(np.zeros((2, 8), np.float32), 10, 0.5)
+    with pytest.raises(RuntimeError, match="No graph has been built"):
+        g.get_graph()
+    with pytest.raises(RuntimeError, match="no graph to store"):
+        g.store()
+    with pytest.raises(IndexError, match="Invalid GPU index"):
+        g.set_gpus([-1])
+    with pytest.raises(IndexError):
+        g.set_gpus([10_000])
+    with pytest.raises(TypeError):
+        g.set_base(np.zeros((4, 4), np.float64))
+    with pytest.raises(TypeError):
+        g.set_base(np.zeros(16, np.float32))
+    g.set_base(np.zeros((64, 8), np.float32))
+    with pytest.raises(RuntimeError, match="different data type"):
+        g.set_base(np.zeros((64, 8), np.uint8))
+
+
+def test_module_surface():
+    """names / defaults of the nanobind module (nanobind.cu:151-300)."""
+    import inspect
+
+    import ggnn
+    import ggnn_amd
+    for name in ("GGNN", "DistanceMeasure", "FloatDataset", "UCharDataset", "IntDataset",
+                 "Evaluator", "Evaluation", "Graph", "set_log_level"):
+        assert hasattr(ggnn, name) and getattr(ggnn, name) is getattr(ggnn_amd, name)
+    assert int(ggnn.DistanceMeasure.Euclidean) == 0 and int(ggnn.DistanceMeasure.Cosine) == 1
+    sig = inspect.signature(ggnn.GGNN.build)
+    assert list(sig.parameters)[1:] == ["k_build", "tau_build", "refinement_iterations", "measure"]
+    assert sig.parameters["refinement_iterations"].default == 2
+    sig = inspect.signature(ggnn.GGNN.query)
+    assert list(sig.parameters)[1:] == ["query", "k_query", "tau_query", "max_iterations",
+                                        "measure"]
+    assert sig.parameters["max_iterations"].default == 400
+    sig = inspect.signature(ggnn.GGNN.bf_query)
+    assert list(sig.parameters)[1:] == ["query", "k_gt", "measure"]
+    assert sig.parameters["k_gt"].default == 100
+    assert list(inspect.signature(ggnn.GGNN.get_graph).parameters)[1:] == ["on_gpu_shard_id"]
+    assert list(inspect.signature(ggnn.GGNN.set_shard_size).parameters)[1:] == ["n_shard"]
+    assert inspect.signature(
+        ggnn.GGNN.set_return_results_on_gpu).parameters["return_results_on_gpu"].default is True
+    assert list(inspect.signature(ggnn.Evaluator.__init__).parameters)[1:] == [
+        "base", "query", "gt", "k_query", "measure"]
+
+
+def test_dataset_xvecs_roundtrip(tmp_path):
+    import ggnn_amd as ggnn
+    a = np.random.default_rng(0).random((37, 24), dtype=np.float32)
+    ds = ggnn.FloatDataset(a)
+    assert (ds.N, ds.D, ds.numel(), ds.device) == (37, 24, 37 * 24, "cpu")
+    f = tmp_path / "x.fvecs"
+    ds.store(str(f))
+    assert os.path.getsize(f) == 37 * (4 + 24 * 4)      # dataset.cu: uint32 D + D values / row
+    back = ggnn.FloatDataset.load(str(f))
+    assert np.array_equal(back.view.numpy(), a)
+    part = ggnn.FloatDataset.load(str(f), 5, 10)
+    assert np.array_equal(part.view.numpy(), a[5:15])
+    b = np.random.default_rng(1).integers(0, 256, (11, 16)).astype(np.uint8)
+    fb = tmp_path / "x.bvecs"
+    ggnn.UCharDataset(b).store(str(fb))
+    assert np.array_equal(ggnn.UCharDataset.load(str(fb)).view.numpy(), b)
+
+
+@pytest.mark.parametrize("measure", [0, 1])
+def test_evaluator_matches_oracle(orc, measure):
+    """ggnn.Evaluator (host logic) against the oracle's restatement of eval.cpp, with duplicated
+    base rows so that the duplicate-aware counters differ from the plain ones."""
+    import ggnn_amd as ggnn
+    r = np.random.default_rng(3)
+    base = r.integers(0, 4, (300, 8)).astype(np.float32) + 1
+    base[100:200] = base[:100]                      # duplicates
+    query = r.integers(0, 4, (40, 8)).astype(np.float32) + 1
+    gt, _ = orc.bf_query(base, query, 20, measure)
+    res = gt[:, :10].copy()
+    res[::3, 0] = gt[::3, 1]                        # perturb some results
+    res[1::4, 5] = 299
+    for K in (10, 5):
+        ev = ggnn.Evaluator(base, query, gt, K, ggnn.DistanceMeasure(measure))
+        got = ev.evaluate_results(res[:, :K].copy())
+        ref = orc.evaluate(base, query, gt, K, res[:, :K].copy(), measure)
+        for name in ref:
+            np.testing.assert_allclose(getattr(got, name), ref[name], rtol=1e-6, err_msg=name)
+        assert "c@1 (=r@1):" in repr(got) and f"r@{K}:" in repr(got)
+    ev = ggnn.Evaluator(np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32), gt, 10)
+    got = ev.evaluate_results(res)
+    ref = orc.evaluate(None, None, gt, 10, res)
+    assert np.isnan(got.c1_dup) and "(duplicates unknown)" in repr(got)
+    np.testing.assert_allclose(got.c_k_query, ref["c_k_query"], rtol=1e-6)
