@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: queries/sec at recall@10 on a SIFT1M-shaped base (+ build time).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: `query()` of the whole
+query set (10 000 x 128 f32, k=10) against the resident graph; inputs are in HBM when the timed
+region starts.  With N GPUs the base is sharded (every rank owns its own 1M-point shard, weak
+scaling), every rank searches the full query set in its shard, candidates are exchanged with an
+RCCL all-gather and merged on the device; the timed step includes the exchange and the merge and
+`value` counts the shard-searches all ranks performed per second (N * Nq / T).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic HBM bytes of the query kernel / its HIP-event duration vs 8 TB/s
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm; the reference has no CPU
+                  path) timed on a bounded sample on this box's host cores (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synthetic(kind, n, d, seed, device):
+    """SIFT-like synthetic vectors: integer values in [0,255] stored as float32 (every fp32 sum
+    of squared differences is exact, so GPU and oracle agree bit for bit).
+      lowrank16: 16-dimensional Gaussian latent mixed into D dims (local intrinsic dimension
+                 comparable to SIFT descriptors), rounded and clipped to [0,255]
+      iid:       i.i.d. uniform integers (no structure; recall targets are not reachable)"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if kind == "iid":
+        return torch.randint(0, 256, (n, d), generator=g, device=device).float()
+    if kind.startswith("lowrank"):
+        latent = int(kind[len("lowrank"):] or 16)
+        ga = torch.Generator(device=device)
+        ga.manual_seed(777)
+        mix = torch.randn(latent, d, generator=ga, device=device) * (40.0 / latent ** 0.5)
+        out = torch.empty((n, d), device=device)
+        for lo in range(0, n, 1 << 20):
+            hi = min(n, lo + (1 << 20))
+            z = torch.randn(hi - lo, latent, generator=g, device=device)
+            out[lo:hi] = (128 + z @ mix).round_().clamp_(0, 255)
+        return out
+    raise ValueError(kind)
+
+
+def recall_at_k(ids, gt):
+    return (ids.unsqueeze(2) == gt.unsqueeze(1)).any(2).float().mean().item()
+
+
+def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=15.0):
+    """Oracle timed on the host cores: brute force (the 'reference CPU brute force' of
+    BASELINE.json, a port because the reference has none) and the traversal port."""
+    from oracle import oracle as orc
+    orc.set_fast_distance(True)  # plain loops, not the lockstep emulation used for parity
+    cores = os.cpu_count() or 1
+    base_h = base.cpu().numpy()
+    q_h = query.cpu().numpy()
+    # calibrate on a few queries, then size the sample for ~budget_s
+    probe = max(1, min(cores, q_h.shape[0]))
+    t = time.perf_counter()
+    orc.bf_query(base_h, q_h[:probe], k, threads=cores)
+    dt = max(time.perf_counter() - t, 1e-3)
+    rate = probe / dt
+    n = int(max(probe, min(q_h.shape[0], rate * budget_s)))
+    t = time.perf_counter()
+    orc.bf_query(base_h, q_h[:n], k, threads=cores)
+    bf_s = time.perf_counter() - t
+    # traversal port on the GPU-built graph
+    nq_t = min(q_h.shape[0], 2000)
+    start = graph["tr"][cfg["STs_offsets"][3]:cfg["STs_offsets"][3] + cfg["Ns"][3]]
+    t = time.perf_counter()
+    orc.query(base_h, q_h[:nq_t], graph["graph0"], start, stats, k, tau, iters, threads=cores)
+    tr_s = time.perf_counter() - t
+    orc.set_fast_distance(False)
+    return {"value": n / bf_s, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"oracle bf_query (port of bf_query_layer.cu), first {n} of "
+                      f"{q_h.shape[0]} queries x {base_h.shape[0]} base rows, {bf_s:.1f} s",
+            "traversal_port_qps": nq_t / tr_s,
+            "traversal_sample": f"oracle query on the GPU-built graph, {nq_t} queries, "
+                                f"{tr_s:.1f} s"}
+
+
+def pmc_traffic(args):
+    """HBM bytes per query_kernel launch from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/*_pmc_hbm.json), corrected
+    as MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 on gfx950 for 16 B/lane loads).
+    Only valid for the default workload; otherwise null."""
+    default = (args.dataset == "lowrank16" and args.n_base == 1_000_000 and args.dim == 128 and
+               args.n_query == 10_000 and args.k == 10 and args.tau_query == 1.0 and
+               args.max_iters == 400 and args.k_build == 24 and args.refine == 2)
+    if not default:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        pmc = json.load(f)["kernels"]
+    for name, c in pmc.items():
+        if "query_kernel" in name and "bf_query" not in name and "FETCH_SIZE" in c:
+            wr = c.get("WRITE_SIZE", {"avg_kb": 0.0})["avg_kb"]
+            return 2.0 * c["FETCH_SIZE"]["avg_kb"] * 1024.0 + wr * 1024.0
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-base", type=int, default=1_000_000, help="base points per GPU")
+    ap.add_argument("--n-query", type=int, default=10_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--k-build", type=int, default=24)
+    ap.add_argument("--tau-build", type=float, default=0.5)
+    ap.add_argument("--refine", type=int, default=2)
+    ap.add_argument("--tau-query", type=float, default=1.0)
+    ap.add_argument("--max-iters", type=int, default=400)
+    ap.add_argument("--dataset", default="lowrank16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import ggnn_amd as ggnn
+    from ggnn_amd.distributed import ShardedGGNN, merge_gathered
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- setup (untimed): data resident in HBM, graph built ----------------------------------
+    base = synthetic(args.dataset, args.n_base, args.dim, 1234 + rank, device)
+    query = synthetic(args.dataset, args.n_query, args.dim, 4321, device)
+    if world > 1:
+        sharded = ShardedGGNN()
+        sharded.set_base(base, is_local_slice=True)
+        eng = sharded.engine
+    else:
+        sharded = None
+        eng = ggnn.GGNN()
+        eng.set_base(base)
+        eng.set_return_results_on_gpu(True)
+    t0 = time.perf_counter()
+    eng.build(args.k_build, args.tau_build, args.refine)
+    torch.cuda.synchronize()
+    build_wall_s = time.perf_counter() - t0
+    build_kernel_s = eng.last_timing_ms()["build_ms"] / 1000.0
+
+    def step():
+        if sharded is not None:
+            return sharded.query(query, args.k, args.tau_query, args.max_iters)
+        return eng.query(query, args.k, args.tau_query, args.max_iters)
+
+    # ground truth by exact brute force on the same data (untimed)
+    gt, _ = (sharded.bf_query(query, args.k) if sharded is not None else eng.bf_query(query, args.k))
+    bf_ms = eng.last_timing_ms()["bf_query_ms"]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, dists = step()
+        kernel_ms.append(eng.last_timing_ms()["query_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    recall = recall_at_k(ids, gt)
+    c1 = (ids[:, 0] == gt[:, 0]).float().mean().item()
+
+    # work counters of one pass (untimed extra run) for the roofline figure
+    eng.set_collect_counters(True)
+    eng.query(query, args.k, args.tau_query, args.max_iters)
+    cnt = eng.last_query_counters()
+    eng.set_collect_counters(False)
+
+    if rank == 0:
+        nq, d, k = args.n_query, args.dim, args.k
+        ms_per_step = elapsed / args.steps * 1000.0
+        value = world * nq / (elapsed / args.steps)
+        # bytes_q = D*s + n_dist*D*s + n_pop*KBuild*4 + S*4 + 8 + K*8
+        alg_bytes = (nq * d * 4 + cnt["n_dist"] * d * 4 + cnt["n_pop"] * args.k_build * 4 +
+                     nq * (32 * 4 + 8 + k * 8))
+        avg_kernel_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "queries/sec @ recall@10 (SIFT1M-shaped, k=10)",
+            "value": value,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.dataset} SIFT1M-shaped {args.n_base}x{d} f32 per GPU, "
+                            f"{nq} queries, k={k}, k_build={args.k_build}, "
+                            f"tau_build={args.tau_build}, refine={args.refine}, "
+                            f"tau_query={args.tau_query}, max_iterations={args.max_iters}",
+                "parallelism": ("single GPU" if world == 1 else
+                                f"base sharded x{world} (one 1M shard per rank), all ranks search "
+                                f"all queries, RCCL all-gather + device merge; value = "
+                                f"{world} x Nq / T"),
+            },
+            "recall_at_10": recall,
+            "c_at_1": c1,
+            "graph_build_s": build_kernel_s,
+            "graph_build_wall_s": build_wall_s,
+            "bf_query_ms": bf_ms,
+            "query_kernel_ms": avg_kernel_ms,
+            "n_dist_per_query": cnt["n_dist"] / nq,
+            "n_pop_per_query": cnt["n_pop"] / nq,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args),
+                         "kernel": "query_kernel<float,16,2,1,L2>",
+                         "note": "algorithmic bytes (every distance = one 512 B row) / HIP-event "
+                                 "kernel time; most rows are served by L2/Infinity Cache"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            graph = eng.get_graph(0)
+            cfg = graph.config
+            g = {"graph0": graph.graph[0].view.numpy(),
+                 "tr": np.concatenate([t.view.numpy().reshape(-1) for t in graph.translation[1:]])}
+            out["cpu_baseline"] = cpu_baseline(base, query, k, g, cfg,
+                                               graph.nn1_stats.view.numpy().reshape(-1),
+                                               args.tau_query, args.max_iters)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""Base-sharded multi-GPU search: one process per GPU, RCCL all-gather of the candidates.
+
+Reference behaviour being replaced (src/ggnn/base/ggnn.cu:278-330, result_merger.cpp:51-149):
+the base is split contiguously into num_gpus x shards_per_gpu shards, one std::thread per GPU
+searches the FULL query set in its shards, results are copied D2H and heap-merged on the CPU
+with global id = partition * shards_per_gpu * N_shard + key.
+
+MI355X-native form: every rank owns one GGNN engine over its slice of the base.  A query runs
+the local traversal, keeps the [Nq, K] candidates on the device, exchanges the packed
+(ids, dists) of all ranks with ONE all-gather each over xGMI (Nq*K*8 bytes per rank -- latency
+bound, so a single un-bucketed collective is right) and merges on the device
+(ggnn_op_merge_results).  With backend "gloo" the same code runs on CPU tensors for tests; the
+merge then uses the device-independent torch implementation below.
+"""
+import torch
+import torch.distributed as dist
+
+from .api import GGNN, DistanceMeasure, _as_tensor
+
+
+def partition_bounds(N, world_size, rank):
+    """contiguous equal split (ggnn.cu:160-200); N must be divisible by world_size"""
+    if N % world_size:
+        raise RuntimeError("base.N needs to be evenly divisible by (N_shard x num_gpus).")
+    n = N // world_size
+    return rank * n, (rank + 1) * n
+
+
+def merge_gathered(parts_ids, parts_dists, k, id_offset_per_part):
+    """k-way merge of [P, Nq, stride] sorted rows; ties -> lower part first.  torch
+    implementation used for CPU tensors (gloo tests); CUDA tensors use the HIP kernel."""
+    if parts_ids.is_cuda:
+        from . import ops
+        return ops.merge_results(parts_ids.contiguous(), parts_dists.contiguous(), k,
+                                 id_offset_per_part)
+    P, Nq, stride = parts_ids.shape
+    offs = (torch.arange(P, dtype=torch.int32) * id_offset_per_part).view(P, 1, 1)
+    ids = (parts_ids + offs).permute(1, 0, 2).reshape(Nq, P * stride)
+    dists = parts_dists.permute(1, 0, 2).reshape(Nq, P * stride)
+    order = torch.sort(dists, dim=1, stable=True).indices[:, :k]
+    return torch.gather(ids, 1, order).contiguous(), torch.gather(dists, 1, order).contiguous()
+
+
+class ShardedGGNN:
+    """`GGNN` over a base that is partitioned across the ranks of a process group.
+
+    Every rank calls the same methods with the same arguments; `set_base` takes either the whole
+    base (each rank keeps its slice) or, with `is_local_slice=True`, the rank's own slice.
+    """
+
+    def __init__(self, group=None, engine=None):
+        """engine: object with the GGNN surface (tests inject a CPU stand-in); default: a GGNN
+        engine on the current device that keeps its results on the GPU."""
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed needs to be initialised first")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        if engine is None:
+            engine = GGNN()
+            engine.set_return_results_on_gpu(True)
+        self.engine = engine
+        self.n_local = None
+
+    def set_base(self, base, is_local_slice=False):
+        t = _as_tensor(base, what="base")
+        if not is_local_slice:
+            lo, hi = partition_bounds(t.shape[0], self.world_size, self.rank)
+            t = t[lo:hi].contiguous()
+        self.n_local = int(t.shape[0])
+        self.engine.set_base(t)
+
+    def build(self, k_build, tau_build, refinement_iterations=2,
+              measure=DistanceMeasure.Euclidean):
+        self.engine.build(k_build, tau_build, refinement_iterations, measure)
+
+    def _exchange(self, ids, dists, k):
+        P = self.world_size
+        nq, stride = ids.shape
+        # dim-0 concatenation layout (valid for RCCL and gloo): [P*Nq, stride] == [P, Nq, stride]
+        g_ids = torch.empty((P * nq, stride), dtype=ids.dtype, device=ids.device)
+        g_dists = torch.empty((P * nq, stride), dtype=dists.dtype, device=dists.device)
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=self.group)
+        return merge_gathered(g_ids.view(P, nq, stride), g_dists.view(P, nq, stride), k,
+                              self.n_local)
+
+    def query(self, query, k_query, tau_query, max_iterations=400,
+              measure=DistanceMeasure.Euclidean):
+        """every rank returns the merged global [Nq, K] result (device tensors)"""
+        ids, dists = self.engine.query(query, k_query, tau_query, max_iterations, measure)
+        return self._exchange(ids, dists, int(k_query))
+
+    def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
+        ids, dists = self.engine.bf_query(query, k_gt, measure)
+        return self._exchange(ids, dists, int(k_gt))

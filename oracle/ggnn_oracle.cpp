@@ -29,6 +29,9 @@ constexpr float INF = std::numeric_limits<float>::infinity();
 constexpr uint32_t L = 4;  // graph_config.h:42-44
 
 double g_margin_min = std::numeric_limits<double>::infinity();
+// bench baseline only: plain 8-accumulator loops instead of the thread/tree emulation
+// (identical results on integer-valued data, where every summation order is exact)
+int g_fast_distance = 0;
 
 // include/ggnn/base/def.h:37-56
 inline uint32_t bit_ceil_u32(uint32_t v)
@@ -63,13 +66,14 @@ void parallel_for(uint32_t n, int threads, F&& f)
   }
   std::atomic<uint32_t> next{0};
   std::vector<std::thread> pool;
+  const uint32_t chunk = std::max(1u, std::min(16u, n / (nt * 4)));
   for (uint32_t t = 0; t < nt; ++t)
     pool.emplace_back([&]() {
       for (;;) {
-        const uint32_t begin = next.fetch_add(16);
+        const uint32_t begin = next.fetch_add(chunk);
         if (begin >= n)
           break;
-        const uint32_t end = std::min(n, begin + 16);
+        const uint32_t end = std::min(n, begin + chunk);
         for (uint32_t i = begin; i < end; ++i)
           f(i);
       }
@@ -147,9 +151,50 @@ struct DistCalc {
   }
 
   // distance.cuh:119-163
+  float distance_fast(uint64_t other) const
+  {
+    const uint32_t D = base.D;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nrm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (base.dtype == ORC_F32) {
+      const float* o = static_cast<const float*>(base.p) + other * D;
+      for (uint32_t d = 0; d < D; ++d) {
+        if (measure == ORC_EUCLIDEAN) {
+          const float diff = o[d] - q[d];
+          acc[d & 7] += diff * diff;
+        }
+        else {
+          acc[d & 7] += o[d] * q[d];
+          nrm[d & 7] += o[d] * o[d];
+        }
+      }
+    }
+    else {
+      const uint8_t* o = static_cast<const uint8_t*>(base.p) + other * D;
+      for (uint32_t d = 0; d < D; ++d) {
+        const float ov = static_cast<float>(o[d]);
+        if (measure == ORC_EUCLIDEAN) {
+          const float diff = ov - q[d];
+          acc[d & 7] += diff * diff;
+        }
+        else {
+          acc[d & 7] += ov * q[d];
+          nrm[d & 7] += ov * ov;
+        }
+      }
+    }
+    const float a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    if (measure == ORC_EUCLIDEAN)
+      return a;
+    const float n = ((nrm[0] + nrm[1]) + (nrm[2] + nrm[3])) + ((nrm[4] + nrm[5]) + (nrm[6] + nrm[7]));
+    const float norm_sqr = q_norm * n;
+    return norm_sqr > 0.f ? std::fabs(1.0f - a / std::sqrt(norm_sqr)) : 1.0f;
+  }
+
   float distance(uint64_t other)
   {
     ++n_calls;
+    if (g_fast_distance)
+      return distance_fast(other);
     const uint32_t D = base.D;
     if (measure == ORC_EUCLIDEAN) {
       for (uint32_t t = 0; t < block; ++t) {
@@ -536,6 +581,11 @@ inline uint32_t radix_key(float f)
 }  // namespace
 
 extern "C" {
+
+void orc_set_fast_distance(int enable)
+{
+  g_fast_distance = enable;
+}
 
 void orc_margin_reset()
 {

@@ -131,6 +131,9 @@ void orc_wave_model_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, float
 
 // smallest relative margin seen in inexact float decisions since the last reset (sym half
 // test); lets tests assert that a seeded input is "decision tie-free".
+// bench cpu_baseline only: compute distances with plain multi-accumulator loops (a fair scalar/
+// SIMD port) instead of the thread-by-thread emulation.  Default off (parity tests).
+void orc_set_fast_distance(int enable);
 void orc_margin_reset();
 double orc_margin_min();
 

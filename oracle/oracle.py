@@ -313,6 +313,10 @@ def op_transform():
     return (3, 0, 0)
 
 
+def set_fast_distance(enable):
+    lib().orc_set_fast_distance(int(bool(enable)))
+
+
 def margin_reset():
     lib().orc_margin_reset()
 

@@ -1,0 +1,41 @@
+"""Condense rocprofv3 CSV output (gpurun_out/) into the tracked summaries under profiles/."""
+import collections, csv, json, os, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+out_dir = "profiles"
+os.makedirs(out_dir, exist_ok=True)
+
+stats = list(csv.DictReader(open(f"{src}/prof_{tag}/bench_kernel_stats.csv")))
+with open(f"{out_dir}/{tag}_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 "
+            "--warmup 3 --no-cpu-baseline   (MI355X, 1 GPU)\n")
+    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    for r in stats:
+        if float(r["Percentage"]) >= 0.001:
+            w.writerow(r)
+
+pmc = {}
+for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    path = f"{src}/{name}_{tag}/bench_counter_collection.csv"
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "ggnn_amd" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc.setdefault(k, {})[counter] = {"launches": len(v), "avg_kb": sum(v) / len(v),
+                                          "last_kb": v[-1], "max_kb": max(v)}
+json.dump({"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- "
+                      "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one pass per counter)",
+           "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 64 B per "
+                    "128 B request for 16 B/lane loads -> multiply by 2 (MI355X_MICROARCH.md, HBM)",
+           "kernels": pmc}, open(f"{out_dir}/{tag}_pmc_hbm.json", "w"), indent=1)
+print(open(f"{out_dir}/{tag}_kernel_stats.csv").read()[:1500])
+q = [v for k, v in pmc.items() if "query_kernel" in k and "bf_" not in k]
+if q:
+    f = q[0]["FETCH_SIZE"]["avg_kb"]
+    wv = q[0].get("WRITE_SIZE", {"avg_kb": 0})["avg_kb"]
+    print("query_kernel HBM bytes/launch (corrected):", 2 * f * 1024 + wv * 1024)
