@@ -95,22 +95,27 @@ def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=15.0):
                                 f"{tr_s:.1f} s"}
 
 
+def workload_string(args):
+    return (f"{args.dataset} SIFT1M-shaped {args.n_base}x{args.dim} f32 per GPU, "
+            f"{args.n_query} queries, k={args.k}, k_build={args.k_build}, "
+            f"tau_build={args.tau_build}, refine={args.refine}, "
+            f"tau_query={args.tau_query}, max_iterations={args.max_iters}")
+
+
 def pmc_traffic(args):
     """HBM bytes per query_kernel launch from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/*_pmc_hbm.json), corrected
     as MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 on gfx950 for 16 B/lane loads).
     Only valid for the default workload; otherwise null."""
-    default = (args.dataset == "lowrank16" and args.n_base == 1_000_000 and args.dim == 128 and
-               args.n_query == 10_000 and args.k == 10 and args.tau_query == 1.0 and
-               args.max_iters == 400 and args.k_build == 24 and args.refine == 2)
-    if not default:
-        return None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
     if not files:
         return None
     with open(files[-1]) as f:
-        pmc = json.load(f)["kernels"]
+        doc = json.load(f)
+    if doc.get("workload") != workload_string(args):
+        return None  # the committed counters were collected on a different workload
+    pmc = doc["kernels"]
     for name, c in pmc.items():
         if "query_kernel" in name and "bf_query" not in name and "FETCH_SIZE" in c:
             wr = c.get("WRITE_SIZE", {"avg_kb": 0.0})["avg_kb"]
@@ -130,8 +135,8 @@ def main():
     ap.add_argument("--k-build", type=int, default=24)
     ap.add_argument("--tau-build", type=float, default=0.5)
     ap.add_argument("--refine", type=int, default=2)
-    ap.add_argument("--tau-query", type=float, default=1.0)
-    ap.add_argument("--max-iters", type=int, default=400)
+    ap.add_argument("--tau-query", type=float, default=0.9)
+    ap.add_argument("--max-iters", type=int, default=200)
     ap.add_argument("--dataset", default="lowrank16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -230,10 +235,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.dataset} SIFT1M-shaped {args.n_base}x{d} f32 per GPU, "
-                            f"{nq} queries, k={k}, k_build={args.k_build}, "
-                            f"tau_build={args.tau_build}, refine={args.refine}, "
-                            f"tau_query={args.tau_query}, max_iterations={args.max_iters}",
+                "workload": workload_string(args),
                 "parallelism": ("single GPU" if world == 1 else
                                 f"base sharded x{world} (one 1M shard per rank), all ranks search "
                                 f"all queries, RCCL all-gather + device merge; value = "

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = r * kWave + lane;
-    int nk = __shfl_down(sl.key[r], 1);
+    int nk = lane_down1(sl.key[r]);
     if (r + 1 < R) {
       const int bk = rdlane(sl.key[r + 1], 0);
       if (lane == 63)

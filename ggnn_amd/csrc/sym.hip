@@ -158,6 +158,8 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+      if (s0 + s * ROWS >= nsurv)
+        break;
       float a, b, nn, dq, dh;
       se.template partial2<MODE>(v[s], a, b, nn);
       se.template finish<MODE>(a, b, nn, dq, dh);

@@ -43,6 +43,25 @@ GGNN_DEV float dpp_f(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// whole-wave shifts by one lane as single DPP moves (gfx9 wave_shr / wave_shl); the boundary
+// lane keeps its own value, like __shfl_up / __shfl_down
+GGNN_DEV int lane_up1(int v)    // lane i <- lane i-1
+{
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+GGNN_DEV int lane_down1(int v)  // lane i <- lane i+1
+{
+  return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);
+}
+GGNN_DEV float lane_up1(float v)
+{
+  return __int_as_float(lane_up1(__float_as_int(v)));
+}
+GGNN_DEV float lane_down1(float v)
+{
+  return __int_as_float(lane_down1(__float_as_int(v)));
+}
+
 // sum over groups of LPR consecutive lanes; every lane of a group receives the group total
 template <int LPR>
 GGNN_DEV float group_sum(float v)
@@ -163,8 +182,8 @@ struct SortedList {
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
       const int i = r * kWave + lane;
-      int pk = __shfl_up(key[r], 1);
-      float pd = __shfl_up(dist[r], 1);
+      int pk = lane_up1(key[r]);
+      float pd = lane_up1(dist[r]);
       if (r > 0) {
         const int bk = rdlane(key[r - 1], 63);
         const float bd = rdlanef(dist[r - 1], 63);
@@ -197,8 +216,8 @@ struct SortedList {
 #pragma unroll
     for (int r = R - 1; r >= 0; --r) {
       const int i = r * kWave + lane;
-      int pk = __shfl_up(key[r], 1);
-      float pd = __shfl_up(dist[r], 1);
+      int pk = lane_up1(key[r]);
+      float pd = lane_up1(dist[r]);
       if (r > 0) {
         const int bk = rdlane(key[r - 1], 63);
         const float bd = rdlanef(dist[r - 1], 63);
@@ -237,8 +256,8 @@ struct SortedList {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = r * kWave + lane;
-      int nk = __shfl_down(key[r], 1);
-      float nd = __shfl_down(dist[r], 1);
+      int nk = lane_down1(key[r]);
+      float nd = lane_down1(dist[r]);
       if (r + 1 < R) {
         const int bk = rdlane(key[r + 1], 0);
         const float bd = rdlanef(dist[r + 1], 0);
@@ -308,14 +327,17 @@ struct SortedList {
     const int E = SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
-    bool found = false;
+    // min over (entry XOR cand) is 0 iff some entry equals cand (pure VALU, no SALU booleans)
+    unsigned acc = 0xffffffffu;
+    const unsigned c = static_cast<unsigned>(cand);
     for (int t = 0; t * 8 < E; ++t) {
       const int4 e = kp[t * 2 + h];
-      found |= (e.x == cand) | (e.y == cand) | (e.z == cand) | (e.w == cand);
+      const unsigned a = min(static_cast<unsigned>(e.x) ^ c, static_cast<unsigned>(e.y) ^ c);
+      const unsigned b = min(static_cast<unsigned>(e.z) ^ c, static_cast<unsigned>(e.w) ^ c);
+      acc = min(acc, min(a, b));
     }
-    const int f = found ? 1 : 0;
-    const int fo = __shfl_xor(f, 32);
-    return (f | fo) ? kEmptyKey : cand;
+    const unsigned other = static_cast<unsigned>(__shfl_xor(static_cast<int>(acc), 32));
+    return (min(acc, other) == 0u) ? kEmptyKey : cand;
   }
 };
 
@@ -480,6 +502,8 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+      if (s0 + s * ROWS >= nsurv)
+        break;  // wave-uniform: no rows left for this and the following steps
       float a, b;
       de.template partial<MODE>(v[s], a, b);
       a = group_sum<DE::LPR>(a);

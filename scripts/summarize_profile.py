@@ -28,7 +28,12 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter] = {"launches": len(v), "avg_kb": sum(v) / len(v),
                                           "last_kb": v[-1], "max_kb": max(v)}
-json.dump({"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- "
+workload = None
+try:
+    workload = json.load(open(f"{src}/bench_prof.json"))["config"]["workload"]
+except Exception:
+    pass
+json.dump({"workload": workload, "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- "
                       "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one pass per counter)",
            "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 64 B per "
                     "128 B request for 16 B/lane loads -> multiply by 2 (MI355X_MICROARCH.md, HBM)",

@@ -320,3 +320,105 @@ def test_end_to_end_shards(orc):
     rec = np.mean([len(set(a) & set(b)) / K for a, b in zip(ids.numpy(), gt.numpy())])
     assert rec > 0.95
     assert (np.diff(d.numpy(), axis=1) >= 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# configuration matrix: element type, dimension (chunk configurations), K (registers per lane)
+# ---------------------------------------------------------------------------------------------
+def _data(dtype, N, D, seed):
+    a = np.random.default_rng(seed).integers(0, 256, (N, D))
+    return a.astype(np.uint8) if dtype == "u8" else a.astype(np.float32)
+
+
+_graph_cache = {}
+
+
+def _mini_graph(orc, dtype, D, K, measure):
+    key = (dtype, D, K, measure)
+    if key not in _graph_cache:
+        N = 1100
+        base = _data(dtype, N, D, 100 + D + K)
+        cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, measure=measure,
+                                               rng=orc.make_rng(N, 11))
+        _graph_cache[key] = dict(N=N, D=D, K=K, base=base, cfg=cfg, graph=graph, tr=tr, sel=sel,
+                                 stats=stats)
+    return _graph_cache[key]
+
+
+CONFIGS = [("u8", 128, 24, 0), ("f32", 96, 24, 0), ("f32", 256, 24, 0), ("f32", 960, 24, 0),
+           ("u8", 960, 24, 0), ("f32", 128, 40, 0), ("f32", 64, 60, 0), ("f32", 128, 24, 1),
+           ("f32", 32, 8, 0)]
+
+
+@pytest.mark.parametrize("dtype,D,K,measure", CONFIGS)
+def test_config_matrix_query_top_merge(ops, orc, dtype, D, K, measure):
+    g = _mini_graph(orc, dtype, D, K, measure)
+    c = g["cfg"]
+    exact = measure == 0
+    q = _data(dtype, 48, D, 7)
+    graph0 = g["graph"][:g["N"]]
+    d_base = dev(g["base"])
+    # query
+    ids, d = ops.query(d_base, dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]), 10,
+                       0.7, 300, measure)
+    o_ids, o_d = orc.query(g["base"], q, graph0, start_points(g), g["stats"], 10, 0.7, 300, measure)
+    if exact:
+        assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
+    else:
+        same = ids.cpu().numpy() == o_ids
+        assert same.mean() > 0.95
+        np.testing.assert_allclose(d.cpu().numpy()[same], o_d[same], rtol=1e-3, atol=1e-6)
+    # top (layer 0 and 1)
+    for layer in (0, 1):
+        tr_l = None if layer == 0 else g["tr"][c.STs_offsets[layer]:c.STs_offsets[layer] + c.Ns[layer]]
+        S, S_off = (c.S0, c.S0_off) if layer == 0 else (c.S, 0)
+        gr, nn1 = ops.top(d_base, K, None if tr_l is None else dev(tr_l), c.Ns[layer], S, S_off,
+                          layer, measure)
+        o_gr, o_nn1 = orc.top(g["base"], K, tr_l, c.Ns[layer], S, S_off, layer, measure)
+        if exact:
+            assert np.array_equal(gr.cpu().numpy(), o_gr)
+            assert np.array_equal(nn1.cpu().numpy(), o_nn1)
+        else:
+            assert (gr.cpu().numpy() == o_gr).mean() > 0.97
+            np.testing.assert_allclose(nn1.cpu().numpy(), o_nn1, rtol=1e-3, atol=1e-6)
+    # merge 3 -> 0 and 2 -> 1
+    for top, btm in ((3, 0), (2, 1)):
+        gb, nn1 = ops.merge(d_base, c, dev(g["graph"]), dev(g["tr"]), dev(g["sel"]),
+                            dev(g["stats"]), 0.5, top, btm, measure)
+        o_gb, o_nn1 = orc.merge(g["base"], c, g["graph"], g["tr"], g["sel"], g["stats"], 0.5, top,
+                                btm, measure)
+        if exact:
+            assert np.array_equal(gb.cpu().numpy(), o_gb)
+            if btm == 0:
+                assert np.array_equal(nn1.cpu().numpy(), o_nn1)
+        else:
+            assert (gb.cpu().numpy() == o_gb).mean() > 0.95
+
+
+@pytest.mark.parametrize("dtype,D,K,measure", [("u8", 128, 24, 0), ("f32", 960, 24, 0),
+                                               ("f32", 64, 60, 0), ("f32", 96, 24, 0)])
+def test_config_matrix_sym(ops, orc, dtype, D, K, measure):
+    g = _mini_graph(orc, dtype, D, K, measure)
+    c = g["cfg"]
+    KF = K // 2
+    Nl = 150
+    graph_l = g["graph"][:c.N].copy()
+    sb = np.full((c.N, KF), -1, np.int32)
+    sa = np.zeros(c.N, np.uint32)
+    orc.margin_reset()
+    orc.sym(g["base"], K, graph_l, None, g["stats"], 0.5, sb, sa, first_n=0, count=Nl,
+            measure=measure)
+    assert orc.margin_min() > 1e-5
+    d_sb = torch.full((c.N, KF), -1, dtype=torch.int32, device="cuda")
+    d_sa = torch.zeros(c.N, dtype=torch.int32, device="cuda")
+    d_base, d_graph, d_stats = dev(g["base"]), dev(graph_l), dev(g["stats"])
+    for n in range(Nl):
+        ops.sym(d_base, K, d_graph, None, d_stats, 0.5, d_sb, d_sa, measure, first_n=n, count=1)
+    assert np.array_equal(d_sa.cpu().numpy().astype(np.uint32), sa)
+    assert np.array_equal(d_sb.cpu().numpy(), sb)
+
+
+def test_unsupported_shapes_fail_loudly(ops):
+    base = torch.zeros((100, 30), dtype=torch.float32, device="cuda")   # 120-byte rows
+    with pytest.raises(RuntimeError, match="multiple of 16 bytes"):
+        ops.bf_query(base, base[:4].contiguous(), 5)
