@@ -246,6 +246,9 @@ def main():
             "graph_build_s": build_kernel_s,
             "graph_build_wall_s": build_wall_s,
             "bf_query_ms": bf_ms,
+            "bf_query": {"ms": bf_ms, "kernel": "bf_mfma_kernel (v_mfma_f32_32x32x2_f32) + exact re-rank",
+                         "tflops": 2.0 * nq * args.n_base * d / (bf_ms * 1e-3) / 1e12,
+                         "mfma_frac_of_f32_peak": 2.0 * nq * args.n_base * d / (bf_ms * 1e-3) / 157.3e12},
             "query_kernel_ms": avg_kernel_ms,
             "n_dist_per_query": cnt["n_dist"] / nq,
             "n_pop_per_query": cnt["n_pop"] / nq,

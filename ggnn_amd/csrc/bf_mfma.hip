@@ -1,0 +1,450 @@
+// bf_query, MFMA path: the exhaustive scan is a true Q x B^T contraction, so it runs on the matrix
+// cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain).
+// Reference being replaced: BruteForceQueryKernel, src/ggnn/query/bf_query_layer.cu:39-65 (N
+// sequential block reductions per query, no reuse of base rows across queries).
+//
+// Structure
+//   1. row_norms_kernel: |b|^2 for every base row, |q|^2 for every query.
+//   2. bf_mfma_kernel: a block = 4 waves x 32 queries; base tiles of 32 rows are staged through
+//      LDS once per block (double buffered) and contracted against the wave's query tile that
+//      lives in registers.  dist = |q|^2 + |b|^2 - 2 q.b (or the cosine form).  Each query keeps
+//      a sorted candidate list of KP = K + margin entries in LDS; a distance enters only if it
+//      beats the list's worst entry (rare after the first tiles), insertion is stable so equal
+//      distances keep the lower base index first (KBestList rule, k_best_list.cuh:92-103).
+//   3. bf_rerank_kernel: the candidates of all base slices are re-evaluated with the reference's
+//      direct formula (DistEngine, distance.cuh:119-163) and ranked by (distance, index), so the
+//      returned distances are the direct-form values; the expanded form only pre-selects.
+//      On integer-valued data (<= 2^24) both forms are exact and the result is bit-identical to
+//      the scan kernel and to the oracle.
+#include "traversal.hpp"
+
+namespace ggnn_amd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBfQueriesPerBlock = 128;
+constexpr int kBfTileRows = 32;
+constexpr uint32_t kBfMaxKP = 64;
+
+struct BfMfmaArgs {
+  const void* base;
+  const void* query;
+  const float* bnorm;
+  const float* qnorm;
+  int32_t* part_ids;   // [slices][Nq][KP]
+  float* part_dists;   // [slices][Nq][KP]
+  uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
+};
+
+// ---- 1. squared norms ---------------------------------------------------------------------------
+template <typename BaseT>
+__global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint32_t N, uint32_t D,
+                                                       float* out)
+{
+  constexpr int EPC = ChunkOf<BaseT>::EPC;
+  using Chunk = typename ChunkOf<BaseT>::type;
+  const uint32_t g = threadIdx.x & 15;
+  const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  float acc = 0.f;
+  if (row < N) {
+    const BaseT* p = data + static_cast<size_t>(row) * D;
+    for (uint32_t e0 = g * EPC; e0 < D; e0 += 16 * EPC) {
+      const Chunk v = *reinterpret_cast<const Chunk*>(p + e0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float x = ChunkOf<BaseT>::get(v, e);
+        acc = fmaf(x, x, acc);
+      }
+    }
+  }
+  acc = group_sum<16>(acc);
+  if (row < N && g == 0)
+    out[row] = acc;
+}
+
+// ---- 2. tile kernel -------------------------------------------------------------------------------
+template <typename BaseT>
+struct TileStage;
+
+// f32: D/4 float4 chunks per row, 32 rows -> 8*D chunks... (D <= 128 => <= 4 per thread)
+template <>
+struct TileStage<float> {
+  float4 r[4];
+  GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end)
+  {
+    const uint32_t cpr = D / 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t idx = threadIdx.x + 256 * e;
+      const uint32_t row = idx / cpr, c4 = idx % cpr;
+      r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < (uint32_t)kBfTileRows && row0 + row < end)
+        r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + 4 * c4);
+    }
+  }
+  GGNN_DEV void store(float* tile, uint32_t D, uint32_t DP) const
+  {
+    const uint32_t cpr = D / 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t idx = threadIdx.x + 256 * e;
+      const uint32_t row = idx / cpr, c4 = idx % cpr;
+      if (row < (uint32_t)kBfTileRows)
+        *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) = r[e];
+    }
+  }
+};
+
+// u8: D/16 chunks of 16 bytes per row, 32 rows -> 2*D <= 256 chunks, one per thread
+template <>
+struct TileStage<uint8_t> {
+  uint4 r;
+  GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end)
+  {
+    const uint32_t cpr = D / 16;
+    const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
+    r = make_uint4(0u, 0u, 0u, 0u);
+    if (row < (uint32_t)kBfTileRows && row0 + row < end)
+      r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + row) * D + 16 * c);
+  }
+  GGNN_DEV void store(float* tile, uint32_t D, uint32_t DP) const
+  {
+    const uint32_t cpr = D / 16;
+    const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
+    if (row < (uint32_t)kBfTileRows) {
+      float* dst = tile + row * DP + 16 * c;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        float4 f;
+        f.x = ChunkOf<uint8_t>::get(r, 4 * w + 0);
+        f.y = ChunkOf<uint8_t>::get(r, 4 * w + 1);
+        f.z = ChunkOf<uint8_t>::get(r, 4 * w + 2);
+        f.w = ChunkOf<uint8_t>::get(r, 4 * w + 3);
+        *reinterpret_cast<float4*>(dst + 4 * w) = f;
+      }
+    }
+  }
+};
+
+template <typename BaseT, int MODE>
+__global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float* tile[2] = {lds_f, lds_f + kBfTileRows * a.DP};
+  float* list_d = lds_f + 2 * kBfTileRows * a.DP;
+  int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const BaseT* query = static_cast<const BaseT*>(a.query);
+  const uint32_t qbase = (blockIdx.x * 4 + wave) * 32;
+  const uint32_t begin = blockIdx.y * a.rows_per_slice;
+  const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
+  const uint32_t KP = a.KP;
+
+  // zero both tiles once: columns >= D (padding of the K dimension) must contribute 0
+  for (uint32_t i = tid; i < 2 * kBfTileRows * a.DP; i += 256)
+    lds_f[i] = 0.f;
+  __syncthreads();
+  // candidate lists of this wave's 32 queries
+  for (uint32_t i = lane; i < 32 * KP; i += 64) {
+    list_d[wave * 32 * KP + i] = inf_f();
+    list_id[wave * 32 * KP + i] = kEmptyKey;
+  }
+
+  // A operand: lane (i=j, h) holds q[qbase+i][h*Dh + kk], kk < Dh (zero outside D / Nq)
+  float aq[64];
+  {
+    const bool qvalid = qbase + j < a.Nq;
+    const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t kk = 4 * t + e;
+        const uint32_t d = h * a.Dh + kk;
+        aq[kk] = (qvalid && kk < a.Dh && d < a.D) ? static_cast<float>(qrow[d]) : 0.f;
+      }
+    }
+  }
+  // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
+  float qn[16], thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
+    thr[r] = qi < a.Nq ? inf_f() : -inf_f();  // padding queries never take the insertion path
+  }
+
+  TileStage<BaseT> stage;
+  const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
+  if (ntiles) {
+    stage.load(base, a.D, begin, end);
+    stage.store(tile[0], a.D, a.DP);
+  }
+  __syncthreads();
+
+  for (uint32_t tt = 0; tt < ntiles; ++tt) {
+    const uint32_t row0 = begin + tt * kBfTileRows;
+    if (tt + 1 < ntiles)
+      stage.load(base, a.D, row0 + kBfTileRows, end);
+    const bool jvalid = row0 + j < end;
+    const float bn = jvalid ? a.bnorm[row0 + j] : 0.f;
+
+    // S = Q x B^T for this wave's 32 queries against the 32 tile rows
+    const float* bt = tile[tt & 1] + j * a.DP + h * a.Dh;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (static_cast<uint32_t>(4 * t) < a.Dh) {
+        const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 0], bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 1], bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 2], bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 3], bv.w, acc, 0, 0, 0);
+      }
+    }
+
+    // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows
+    bool refresh = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float d;
+      if (MODE == kL2) {
+        d = fmaf(-2.0f, acc[r], qn[r] + bn);
+      }
+      else {
+        const float norm_sqr = qn[r] * bn;
+        d = (norm_sqr > 0.0f) ? fabsf(1.0f - acc[r] / sqrtf(norm_sqr)) : 1.0f;
+      }
+      if (!jvalid)
+        d = inf_f();
+      unsigned long long m = __ballot(d < thr[r]);
+      if (m) {
+        refresh = true;
+        // rare path: stable insertion, candidates in ascending lane order (= ascending base
+        // index within each query row)
+        while (m) {
+          const int l = __ffsll(static_cast<long long>(m)) - 1;
+          m &= m - 1;
+          const float dl = rdlanef(d, l);
+          const int qi = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          if (qbase + qi >= a.Nq)
+            continue;
+          float* Ld = list_d + (wave * 32 + qi) * KP;
+          int* Li = list_id + (wave * 32 + qi) * KP;
+          if (!(dl < Ld[KP - 1]))
+            continue;
+          const int id = static_cast<int>(row0 + (l & 31));
+          // lane k < KP owns entry k
+          const bool own = lane < (int)KP;
+          const float cur = own ? Ld[lane] : inf_f();
+          const int curi = own ? Li[lane] : kEmptyKey;
+          const float prev = (own && lane > 0) ? Ld[lane - 1] : -inf_f();
+          const int previ = (own && lane > 0) ? Li[lane - 1] : kEmptyKey;
+          // one wave: the loads above are issued for all lanes before the stores below (LDS
+          // operations of a wave execute in order); only the compiler must not reorder them
+          __builtin_amdgcn_wave_barrier();
+          if (own && dl < cur) {
+            const bool first = !(dl < prev);  // previous entry stays: insert here
+            Ld[lane] = first ? dl : prev;
+            Li[lane] = first ? id : previ;
+          }
+          __builtin_amdgcn_wave_barrier();
+          (void)curi;
+        }
+      }
+    }
+    if (refresh) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (qbase + qi < a.Nq)
+          thr[r] = list_d[(wave * 32 + qi) * KP + KP - 1];
+      }
+    }
+
+    if (tt + 1 < ntiles)
+      stage.store(tile[(tt + 1) & 1], a.D, a.DP);
+    __syncthreads();
+  }
+
+  // partial results of this base slice
+  for (uint32_t i = lane; i < 32 * KP; i += 64) {
+    const uint32_t qi = qbase + i / KP;
+    if (qi < a.Nq) {
+      const size_t o = (static_cast<size_t>(blockIdx.y) * a.Nq + qi) * KP + i % KP;
+      a.part_ids[o] = list_id[wave * 32 * KP + i];
+      a.part_dists[o] = list_d[wave * 32 * KP + i];
+    }
+  }
+}
+
+// ---- 3. exact re-rank ----------------------------------------------------------------------------
+struct BfRerankArgs {
+  const void* base;
+  const void* query;
+  const int32_t* part_ids;
+  int32_t* ids;
+  float* dists;
+  uint32_t D, Nq, K, KP, slices, cap;
+};
+
+template <typename BaseT, int LPR, int NCH, int MODE>
+__global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const WaveLds lds(lds_raw, 2 * a.cap);
+  float* all_d = reinterpret_cast<float*>(lds.known);
+  int* all_id = lds.known + a.cap;
+  const int lane = threadIdx.x;
+  const uint32_t n = blockIdx.x;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  DistEngine<BaseT, LPR, NCH> de;
+  de.template load_query<MODE>(base, a.D, static_cast<const BaseT*>(a.query) + static_cast<size_t>(n) * a.D);
+
+  const uint32_t total = a.slices * a.KP;
+  uint32_t count = 0;
+  for (uint32_t c0 = 0; c0 < total; c0 += kKBlock) {
+    const uint32_t c = c0 + lane;
+    int cand = kEmptyKey;
+    if (lane < (int)kKBlock && c < total)
+      cand = a.part_ids[(static_cast<size_t>(c / a.KP) * a.Nq + n) * a.KP + c % a.KP];
+    const unsigned long long surv = __ballot(cand != kEmptyKey);
+    const int nsurv = __popcll(surv);
+    if (!nsurv)
+      continue;
+    __syncthreads();
+    if (cand != kEmptyKey)
+      lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
+    __syncthreads();
+    compute_distances<MODE>(de, lds, nsurv, nullptr);
+    __syncthreads();
+    if (lane < nsurv) {
+      all_d[count + lane] = lds.cd0[lane];
+      all_id[count + lane] = lds.ckeys[lane];
+    }
+    count += nsurv;
+  }
+  __syncthreads();
+  int32_t* out_i = a.ids + static_cast<size_t>(n) * a.K;
+  float* out_d = a.dists + static_cast<size_t>(n) * a.K;
+  for (uint32_t i = lane; i < count; i += kWave) {
+    const float d = all_d[i];
+    const int id = all_id[i];
+    uint32_t rank = 0;
+    for (uint32_t jj = 0; jj < count; ++jj) {
+      const float dj = all_d[jj];
+      rank += (dj < d) || (dj == d && all_id[jj] < id);
+    }
+    if (rank < a.K) {
+      out_i[rank] = id;
+      out_d[rank] = d;
+    }
+  }
+  for (uint32_t k = count + lane; k < a.K; k += kWave) {
+    out_i[k] = kEmptyKey;
+    out_d[k] = inf_f();
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+bool bf_mfma_supported(const BfLaunch& a)
+{
+  const uint32_t epc = a.dtype == GGNN_F32 ? 4 : 16;
+  return a.D <= 128 && a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 &&
+         a.N_base >= 4096;
+}
+
+void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
+{
+  check_vector_layout(a.base, a.D, a.dtype);
+  check_vector_layout(a.query, a.D, a.dtype);
+  const uint32_t KP = a.k_query + 8;  // margin against rounding of the expanded distance form
+  const uint32_t Dh = ((a.D + 1) / 2 + 3) / 4 * 4;
+  const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
+  const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
+  uint32_t slices = std::max(1u, std::min(32u, (768u + qblocks - 1) / qblocks));
+  uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
+  rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
+  slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
+
+  float* norms = nullptr;
+  int32_t* part_ids = nullptr;
+  float* part_dists = nullptr;
+  const size_t parts = static_cast<size_t>(slices) * a.Nq * KP;
+  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&norms),
+                                (static_cast<size_t>(a.N_base) + a.Nq) * 4, stream));
+  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part_ids), parts * 4, stream));
+  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part_dists), parts * 4, stream));
+  float* bnorm = norms;
+  float* qnorm = norms + a.N_base;
+
+  BfMfmaArgs m{};
+  m.base = a.base;
+  m.query = a.query;
+  m.bnorm = bnorm;
+  m.qnorm = qnorm;
+  m.part_ids = part_ids;
+  m.part_dists = part_dists;
+  m.D = a.D;
+  m.Dh = Dh;
+  m.DP = DP;
+  m.Nq = a.Nq;
+  m.N_base = a.N_base;
+  m.KP = KP;
+  m.slices = slices;
+  m.rows_per_slice = rows_per_slice;
+  const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP) * sizeof(float);
+  GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
+
+  BfRerankArgs rr{};
+  rr.base = a.base;
+  rr.query = a.query;
+  rr.part_ids = part_ids;
+  rr.ids = a.ids;
+  rr.dists = a.dists;
+  rr.D = a.D;
+  rr.Nq = a.Nq;
+  rr.K = a.k_query;
+  rr.KP = KP;
+  rr.slices = slices;
+  rr.cap = (slices * KP + 3) / 4 * 4;
+  const size_t rr_lds = wave_lds_bytes(2 * rr.cap);
+
+#define GGNN_BF_MFMA(T, MODE_)                                                                    \
+  do {                                                                                            \
+    hipLaunchKernelGGL((row_norms_kernel<T>), dim3((a.N_base + 15) / 16), dim3(256), 0, stream,   \
+                       static_cast<const T*>(a.base), a.N_base, a.D, bnorm);                      \
+    hipLaunchKernelGGL((row_norms_kernel<T>), dim3((a.Nq + 15) / 16), dim3(256), 0, stream,       \
+                       static_cast<const T*>(a.query), a.Nq, a.D, qnorm);                         \
+    if (lds > 64 * 1024)                                                                          \
+      GGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                                         static_cast<int>(lds)));                                 \
+    hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_>), dim3(qblocks, slices), dim3(256), lds, stream, \
+                       m);                                                                        \
+    hipLaunchKernelGGL((bf_rerank_kernel<T, 16, 2, MODE_>), dim3(a.Nq), dim3(kWave), rr_lds,      \
+                       stream, rr);                                                               \
+  } while (0)
+  if (a.dtype == GGNN_F32) {
+    if (a.measure == GGNN_EUCLIDEAN)
+      GGNN_BF_MFMA(float, kL2);
+    else
+      GGNN_BF_MFMA(float, kCos);
+  }
+  else {
+    if (a.measure == GGNN_EUCLIDEAN)
+      GGNN_BF_MFMA(uint8_t, kL2);
+    else
+      GGNN_BF_MFMA(uint8_t, kCos);
+  }
+#undef GGNN_BF_MFMA
+  GGNN_HIP_CHECK(hipGetLastError());
+  GGNN_HIP_CHECK(hipFreeAsync(norms, stream));
+  GGNN_HIP_CHECK(hipFreeAsync(part_ids, stream));
+  GGNN_HIP_CHECK(hipFreeAsync(part_dists, stream));
+}
+
+}  // namespace ggnn_amd

@@ -7,6 +7,8 @@
 // per (query, base slice), 64/LPR base rows per coalesced 16 B/lane load instruction, K-best
 // list in registers.  Slices are merged by a second tiny kernel.  (An MFMA Q x B^T tile path
 // for large query batches is planned on top of this parity anchor, see DESIGN.md.)
+#include <cstdlib>
+
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -116,10 +118,22 @@ static void launch_bf_r(const BfArgs& args, hipStream_t stream)
     throw Error(GGNN_UNSUPPORTED, "bf_query supports k_gt <= 256 in this build");
 }
 
+bool bf_mfma_supported(const BfLaunch& a);
+void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream);
+
 void launch_bf_query(const BfLaunch& a, hipStream_t stream)
 {
   if (a.Nq == 0)
     return;
+  // large batches: Q x B^T on the matrix cores (bf_mfma.hip); GGNN_BF_SCAN=1 forces the scan
+  static const bool force_scan = [] {
+    const char* e = std::getenv("GGNN_BF_SCAN");
+    return e && e[0] == '1';
+  }();
+  if (!force_scan && bf_mfma_supported(a)) {
+    launch_bf_query_mfma(a, stream);
+    return;
+  }
   check_vector_layout(a.base, a.D, a.dtype);
   check_vector_layout(a.query, a.D, a.dtype);
   GGNN_REQUIRE(a.k_query >= 1 && a.k_query <= 6000, GGNN_INVALID_ARGUMENT,

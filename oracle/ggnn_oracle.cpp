@@ -688,6 +688,34 @@ void orc_bf_query(const void* base, uint32_t N, uint32_t D, int dtype, const voi
   const uint32_t block = std::max(32u, bit_ceil_u32((D + 3) / 4));
   BaseView b{base, dtype, D};
   BaseView qv{query, dtype, D};
+  if (g_fast_distance) {
+    // bench baseline: same scan, but every base row is reused for a group of queries so that
+    // the host is not purely DRAM-bound (results are identical: per-query visiting order and
+    // KBestList rule are unchanged)
+    constexpr uint32_t G = 16;
+    parallel_for((Nq + G - 1) / G, threads, [&](uint32_t grp) {
+      const uint32_t q0 = grp * G, qn = std::min(G, Nq - q0);
+      std::vector<DistCalc> dcs;
+      std::vector<KBest> bests;
+      for (uint32_t g = 0; g < qn; ++g) {
+        dcs.emplace_back(b, measure, block, 4);
+        dcs.back().load_query(qv, q0 + g);
+        bests.emplace_back(K, block);
+      }
+      for (uint32_t i = 0; i < N; ++i)
+        for (uint32_t g = 0; g < qn; ++g) {
+          const float d = dcs[g].distance_fast(i);
+          if (d < bests[g].worst())
+            bests[g].add_unique(d, (int32_t)i);
+        }
+      for (uint32_t g = 0; g < qn; ++g)
+        for (uint32_t k = 0; k < K; ++k) {
+          out_ids[(size_t)(q0 + g) * K + k] = bests[g].id[k];
+          out_dists[(size_t)(q0 + g) * K + k] = bests[g].d[k];
+        }
+    });
+    return;
+  }
   parallel_for(Nq, threads, [&](uint32_t n) {
     DistCalc dc(b, measure, block, 4);
     dc.load_query(qv, n);

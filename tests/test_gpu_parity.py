@@ -422,3 +422,37 @@ def test_unsupported_shapes_fail_loudly(ops):
     base = torch.zeros((100, 30), dtype=torch.float32, device="cuda")   # 120-byte rows
     with pytest.raises(RuntimeError, match="multiple of 16 bytes"):
         ops.bf_query(base, base[:4].contiguous(), 5)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf_query, MFMA path (taken for >= 256 queries, D <= 128, k <= 56): Q x B^T pre-selection on
+# the matrix cores + exact direct-form re-rank -> same answers as the scan kernel / the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,N,D,Nq,K", [("f32", 20000, 128, 300, 10), ("u8", 20000, 128, 257, 10),
+                                            ("f32", 9000, 96, 400, 24), ("f32", 5000, 32, 1000, 1),
+                                            ("f32", 33333, 100, 256, 50), ("f32", 4100, 4, 260, 5)])
+def test_bf_mfma_int_exact(ops, orc, dtype, N, D, Nq, K):
+    base, q = _data(dtype, N, D, 61), _data(dtype, Nq, D, 62)
+    ids, d = ops.bf_query(dev(base), dev(q), K)
+    o_ids, o_d = orc.bf_query(base, q, K)
+    assert np.array_equal(ids.cpu().numpy(), o_ids)
+    assert np.array_equal(d.cpu().numpy(), o_d)
+
+
+def test_bf_mfma_ties_and_duplicates(ops, orc):
+    base = make_int_data(3000, 64, 3)
+    base = np.concatenate([base, base, base])           # every distance occurs three times
+    q = np.concatenate([make_int_data(200, 64, 4), base[:100]])  # includes exact hits (d = 0)
+    ids, d = ops.bf_query(dev(base), dev(q), 12)
+    o_ids, o_d = orc.bf_query(base, q, 12)
+    assert np.array_equal(ids.cpu().numpy(), o_ids)
+    assert np.array_equal(d.cpu().numpy(), o_d)
+
+
+@pytest.mark.parametrize("measure", [0, 1])
+def test_bf_mfma_float_tolerance(ops, orc, measure):
+    base, q = make_uni_data(30000, 128, 7), make_uni_data(300, 128, 8)
+    ids, d = ops.bf_query(dev(base), dev(q), 10, measure)
+    o_ids, o_d = orc.bf_query(base, q, 10, measure)
+    np.testing.assert_allclose(d.cpu().numpy(), o_d, rtol=RTOL, atol=1e-7)
+    assert (ids.cpu().numpy() == o_ids).mean() > 0.99
