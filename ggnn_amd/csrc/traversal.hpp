@@ -14,6 +14,8 @@
 // gathers), then the accept/push sequence is replayed in candidate order, which is what the
 // reference does one candidate at a time (simple_knn_cache.cuh:268-286).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace ggnn_amd {
@@ -391,7 +393,8 @@ struct DistEngine {
   uint32_t D;
   int g;  // lane within the row group
   Chunk q[NCH];
-  float q_norm;  // cosine: |q|^2
+  float q_norm;    // cosine: |q|^2
+  uint32_t qq_u8;  // uint8 rows: sum of squares of this lane's query elements
 
   GGNN_DEV bool chunk_valid(int c) const
   {
@@ -428,12 +431,47 @@ struct DistEngine {
     q_norm = 0.f;
     if (MODE == kCos)
       q_norm = group_sum<LPR>(nrm);
+    qq_u8 = 0;
+    if constexpr (std::is_same<BaseT, uint8_t>::value) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        qq_u8 = __builtin_amdgcn_udot4(q[c].x, q[c].x, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(q[c].y, q[c].y, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(q[c].z, q[c].z, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(q[c].w, q[c].w, qq_u8, false);
+      }
+    }
   }
 
   // per-lane partial sums over the lane's chunks of one row
   template <int MODE>
   GGNN_DEV void partial(const Chunk (&v)[NCH], float& a, float& b) const
   {
+    if constexpr (std::is_same<BaseT, uint8_t>::value) {
+      // packed integer arithmetic (v_dot4_u32_u8), exact: sum (o-q)^2 = sum o^2 + sum q^2 - 2 sum oq.
+      // Equals the reference's float accumulation whenever that is exact (D <= 258).
+      uint32_t ab = 0, bb = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        ab = __builtin_amdgcn_udot4(v[c].x, q[c].x, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].y, q[c].y, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].z, q[c].z, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].w, q[c].w, ab, false);
+        bb = __builtin_amdgcn_udot4(v[c].x, v[c].x, bb, false);
+        bb = __builtin_amdgcn_udot4(v[c].y, v[c].y, bb, false);
+        bb = __builtin_amdgcn_udot4(v[c].z, v[c].z, bb, false);
+        bb = __builtin_amdgcn_udot4(v[c].w, v[c].w, bb, false);
+      }
+      if (MODE == kL2) {
+        a = static_cast<float>((qq_u8 + bb) - 2u * ab);
+        b = 0.f;
+      }
+      else {
+        a = static_cast<float>(ab);
+        b = static_cast<float>(bb);
+      }
+      return;
+    }
     a = 0.f;
     b = 0.f;
 #pragma unroll
@@ -558,6 +596,10 @@ inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
 {
   const uint32_t epc = dtype == GGNN_F32 ? 4 : 16;
   const uint32_t chunks = (D + epc - 1) / epc;
+  if (chunks <= 8)
+    return {8, 1};
+  if (chunks <= 16)
+    return {8, 2};
   if (chunks <= 32)
     return {16, 2};
   if (chunks <= 64)
@@ -572,13 +614,17 @@ inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
   do {                                                                            \
     const ::ggnn_amd::DistConfig _dc = ::ggnn_amd::pick_dist_config((D), (dtype)); \
     if ((dtype) == GGNN_F32) {                                                    \
-      if (_dc.lpr == 16 && _dc.nch == 2) { F(float, 16, 2); }                     \
+      if (_dc.lpr == 8 && _dc.nch == 1) { F(float, 8, 1); }                       \
+      else if (_dc.lpr == 8 && _dc.nch == 2) { F(float, 8, 2); }                  \
+      else if (_dc.lpr == 16 && _dc.nch == 2) { F(float, 16, 2); }                \
       else if (_dc.lpr == 16 && _dc.nch == 4) { F(float, 16, 4); }                \
       else if (_dc.lpr == 64 && _dc.nch == 4) { F(float, 64, 4); }                \
       else { F(float, 64, 16); }                                                  \
     }                                                                             \
     else {                                                                        \
-      if (_dc.lpr == 16 && _dc.nch == 2) { F(uint8_t, 16, 2); }                   \
+      if (_dc.lpr == 8 && _dc.nch == 1) { F(uint8_t, 8, 1); }                     \
+      else if (_dc.lpr == 8 && _dc.nch == 2) { F(uint8_t, 8, 2); }                \
+      else if (_dc.lpr == 16 && _dc.nch == 2) { F(uint8_t, 16, 2); }              \
       else if (_dc.lpr == 16 && _dc.nch == 4) { F(uint8_t, 16, 4); }              \
       else if (_dc.lpr == 64 && _dc.nch == 4) { F(uint8_t, 64, 4); }              \
       else { F(uint8_t, 64, 16); }                                                \

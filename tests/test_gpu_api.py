@@ -1,0 +1,152 @@
+"""GPU tests of the ggnn.GGNN surface beyond the kernels: device-resident inputs, results on the
+GPU, shards, store/load, counters (all through the C-ABI handle API)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_int_data
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def recall(a, b):
+    return np.mean([len(set(x) & set(y)) / len(y) for x, y in zip(a, b)])
+
+
+@pytest.fixture(scope="module")
+def data():
+    return make_int_data(5000, 64, 71), make_int_data(150, 64, 72)
+
+
+def test_gpu_inputs_and_results_on_gpu(data):
+    import ggnn_amd as ggnn
+    base, q = data
+    eng = ggnn.GGNN()
+    eng.set_base(torch.from_numpy(base).cuda())           # examples/python/ggnn_pytorch_gpu_data.py
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5)
+    ids, d = eng.query(torch.from_numpy(q).cuda(), 10, 0.7, 400)
+    assert ids.is_cuda and d.is_cuda and tuple(ids.shape) == (150, 10)
+    gt, gd = eng.bf_query(torch.from_numpy(q).cuda(), 10)
+    assert gt.is_cuda
+    assert recall(ids.cpu().numpy(), gt.cpu().numpy()) > 0.95
+    # the same engine answers host queries identically
+    eng.set_return_results_on_gpu(False)
+    ids2, d2 = eng.query(q, 10, 0.7, 400)
+    assert not ids2.is_cuda
+    assert np.array_equal(ids2.numpy(), ids.cpu().numpy()) and np.array_equal(d2.numpy(), d.cpu().numpy())
+
+
+def test_base_reference_is_borrowed(data):
+    import ggnn_amd as ggnn
+    base, q = data
+    t = torch.from_numpy(base).cuda()
+    eng = ggnn.GGNN()
+    eng.set_base_reference(t)
+    eng.build(24, 0.5, 1)
+    ids, _ = eng.query(q, 10, 0.7)
+    gt, _ = eng.bf_query(q, 10)
+    assert recall(ids.numpy(), gt.numpy()) > 0.95
+
+
+def test_shards_results_on_gpu_are_unmerged_sorted_rows(data, orc):
+    import ggnn_amd as ggnn
+    base, q = data
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_shard_size(1250)                                # 4 shards on one GPU
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 1)
+    ids, d = eng.query(q, 10, 0.7)
+    assert tuple(ids.shape) == (150, 40)                    # ggnn.cuh:108-113: N*K sorted results
+    dn = d.cpu().numpy()
+    assert (np.diff(dn, axis=1) >= 0).all()
+    assert ids.cpu().numpy().min() >= 0 and ids.cpu().numpy().max() < 5000
+    eng.set_return_results_on_gpu(False)
+    ids2, d2 = eng.query(q, 10, 0.7)
+    assert np.array_equal(ids2.numpy(), ids.cpu().numpy()[:, :10])
+    # every shard is an independent graph: per-shard oracle query + reference merge == engine
+    for s in range(4):
+        g = eng.get_graph(s)
+        assert g.config["N"] == 1250
+    parts_i, parts_d = [], []
+    for s in range(4):
+        g = eng.get_graph(s)
+        o = orc.query(base[s * 1250:(s + 1) * 1250], q, g.graph[0].view.numpy(),
+                      g.translation[3].view.numpy().reshape(-1),
+                      g.nn1_stats.view.numpy().reshape(-1), 10, 0.7, 400)
+        parts_i.append(o[0] + s * 1250)
+        parts_d.append(o[1])
+    allr = orc.sort_shard_results(np.concatenate(parts_i, 1), np.concatenate(parts_d, 1))
+    assert np.array_equal(allr[1], dn)
+    uniq = np.ones_like(dn, bool)
+    uniq[:, 1:] &= dn[:, 1:] != dn[:, :-1]
+    uniq[:, :-1] &= dn[:, :-1] != dn[:, 1:]
+    assert np.array_equal(allr[0][uniq], ids.cpu().numpy()[uniq])
+
+
+def test_store_load_roundtrip(data, tmp_path):
+    import ggnn_amd as ggnn
+    base, q = data
+    a = ggnn.GGNN()
+    a.set_base(base)
+    a.set_working_directory(str(tmp_path))
+    a.set_shard_size(2500)
+    a.build(24, 0.5, 1)
+    a.store()
+    cfg = a.get_graph(0).config
+    expect = (cfg["N_all"] * 24 + 2 * cfg["ST_all"]) * 4 + 8   # graph.cpp:48-91 pool layout
+    for s in (0, 1):
+        assert os.path.getsize(tmp_path / f"part_{s}.ggnn") == expect
+    ids_a, d_a = a.query(q, 10, 0.7)
+    b = ggnn.GGNN()
+    b.set_base(base)
+    b.set_working_directory(str(tmp_path))
+    b.set_shard_size(2500)
+    b.load(24)
+    ids_b, d_b = b.query(q, 10, 0.7)
+    assert np.array_equal(ids_a.numpy(), ids_b.numpy()) and np.array_equal(d_a.numpy(), d_b.numpy())
+    c = ggnn.GGNN()
+    c.set_base(base)
+    c.set_working_directory(str(tmp_path / "empty"))
+    with pytest.raises(RuntimeError, match="graph file"):
+        c.load(24)
+
+
+def test_counters_and_timing(data):
+    import ggnn_amd as ggnn
+    base, q = data
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.build(24, 0.5, 0)
+    eng.set_collect_counters(True)
+    eng.query(q, 10, 0.6, 200)
+    c = eng.last_query_counters()
+    t = eng.last_timing_ms()
+    assert c["n_pop"] > 0 and c["n_dist"] >= 32 * 150 and c["n_pop"] <= 200 * 150
+    assert t["build_ms"] > 0 and t["query_ms"] > 0
+
+
+def test_misuse_after_build(data):
+    import ggnn_amd as ggnn
+    base, q = data
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.build(24, 0.5, 0)
+    with pytest.raises(RuntimeError, match="already been built"):
+        eng.build(24, 0.5, 0)
+    with pytest.raises(RuntimeError, match="cannot be changed"):
+        eng.set_base(base)
+    with pytest.raises(RuntimeError, match="data type"):
+        eng.query(q.astype(np.uint8), 10, 0.5)
+    with pytest.raises(RuntimeError, match="dimension"):
+        eng.query(np.zeros((3, 32), np.float32), 10, 0.5)
+    with pytest.raises(RuntimeError, match="does not exist"):
+        eng.get_graph(3)
+    e2 = ggnn.GGNN()
+    e2.set_base(base)
+    e2.set_shard_size(1234)
+    with pytest.raises(RuntimeError, match="evenly divisible"):
+        e2.build(24, 0.5)
