@@ -144,7 +144,9 @@ struct ggnn_handle {
   DeviceBuffer base_dev_copy;
   const void* d_base{nullptr};
   uint64_t base_N{0};
-  uint32_t base_D{0};
+  uint32_t base_D{0};  // dimension as given by the caller
+  uint32_t pad_D{0};   // row length the kernels see: rows are zero-padded to a multiple of 16 bytes
+                       // (zeros change neither the L2 nor the cosine distance)
   ggnn_dtype base_dtype{GGNN_F32};
   bool base_set{false};
 
@@ -196,21 +198,24 @@ struct ggnn_handle {
     if (d_base)
       return;
     GGNN_REQUIRE(base_set, GGNN_INVALID_STATE, "The base needs to be set first.");
-    const size_t bytes = base_N * base_D * dtype_size(base_dtype);
-    if (base_loc == GGNN_GPU && base_gpu == device && base_dev_copy.p == nullptr) {
-      d_base = base_src;  // borrowed device memory on the right GPU
-      return;
-    }
-    if (base_dev_copy.p && base_gpu == device) {
-      d_base = base_dev_copy.p;
-      return;
-    }
-    DeviceBuffer staged(bytes);
+    const size_t es = dtype_size(base_dtype);
+    const bool padded = pad_D != base_D;
     const void* src = base_dev_copy.p ? base_dev_copy.p : base_src;
-    GGNN_HIP_CHECK(hipMemcpyAsync(staged.p, src, bytes,
-                                  base_loc == GGNN_GPU ? hipMemcpyDeviceToDevice
-                                                       : hipMemcpyHostToDevice,
-                                  stream));
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+    if (!padded && aligned && base_loc == GGNN_GPU && base_gpu == device) {
+      d_base = src;  // device memory on the right GPU (borrowed or our own copy)
+      return;
+    }
+    DeviceBuffer staged(base_N * pad_D * es);
+    const hipMemcpyKind kind =
+        base_loc == GGNN_GPU ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (padded) {
+      GGNN_HIP_CHECK(hipMemsetAsync(staged.p, 0, staged.bytes, stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(staged.p, pad_D * es, src, base_D * es, base_D * es, base_N,
+                                      kind, stream));
+    }
+    else
+      GGNN_HIP_CHECK(hipMemcpyAsync(staged.p, src, staged.bytes, kind, stream));
     GGNN_HIP_CHECK(hipStreamSynchronize(stream));
     base_dev_copy = std::move(staged);
     base_gpu = device;
@@ -223,7 +228,7 @@ struct ggnn_handle {
   const void* shard_base(uint32_t shard) const
   {
     return static_cast<const uint8_t*>(d_base) +
-           static_cast<size_t>(shard) * cfg.N * base_D * dtype_size(base_dtype);
+           static_cast<size_t>(shard) * cfg.N * pad_D * dtype_size(base_dtype);
   }
 
   // GGNNImpl::prepare, ggnn.cu:154-203
@@ -249,7 +254,7 @@ struct ggnn_handle {
                  "base.N needs to be evenly divisible by (N_shard x num_gpus).");
     GGNN_REQUIRE(base_N < 0x7fffffffull, GGNN_INVALID_ARGUMENT,
                  "ids are int32: at most 2^31-1 base points per engine");
-    graph_config_init(static_cast<uint32_t>(n), base_D, KBuild, &cfg);
+    graph_config_init(static_cast<uint32_t>(n), pad_D, KBuild, &cfg);
     num_shards = static_cast<uint32_t>(spg);
     stage_base();
     shards.clear();
@@ -289,7 +294,7 @@ struct ggnn_handle {
       };
       auto do_merge = [&](uint32_t top, uint32_t btm) {
         if (top == btm) {
-          TopLaunch t{base,        base_dtype,          base_D,
+          TopLaunch t{base,        base_dtype,          pad_D,
                       measure,     K,                   layer_tr(btm),
                       cfg.Ns[btm], btm ? cfg.S : cfg.S0, btm ? 0u : cfg.S0_off,
                       btm,         layer_graph(btm),    nn1_dist.as<float>()};
@@ -332,7 +337,7 @@ struct ggnn_handle {
         SymLaunch s{base,
                     base_dtype,
                     measure,
-                    base_D,
+                    pad_D,
                     K,
                     layer_graph(layer),
                     layer_tr(layer),
@@ -389,13 +394,20 @@ struct ggnn_handle {
     if (!Nq)
       return s;
     GGNN_REQUIRE(q != nullptr, GGNN_INVALID_ARGUMENT, "query pointer is null");
-    if (loc == GGNN_GPU) {
+    const size_t es = dtype_size(dtype);
+    const bool padded = pad_D != base_D;
+    if (loc == GGNN_GPU && !padded && (reinterpret_cast<uintptr_t>(q) & 15u) == 0) {
       s.ptr = q;
       return s;
     }
-    const size_t bytes = Nq * D * dtype_size(dtype);
-    s.owned.alloc(bytes);
-    GGNN_HIP_CHECK(hipMemcpyAsync(s.owned.p, q, bytes, hipMemcpyHostToDevice, stream));
+    const hipMemcpyKind kind = loc == GGNN_GPU ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    s.owned.alloc(Nq * pad_D * es);
+    if (padded) {
+      GGNN_HIP_CHECK(hipMemsetAsync(s.owned.p, 0, s.owned.bytes, stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(s.owned.p, pad_D * es, q, D * es, D * es, Nq, kind, stream));
+    }
+    else
+      GGNN_HIP_CHECK(hipMemcpyAsync(s.owned.p, q, s.owned.bytes, kind, stream));
     s.ptr = s.owned.p;
     return s;
   }
@@ -449,7 +461,7 @@ struct ggnn_handle {
                      sq.ptr,
                      base_dtype,
                      cfg.N,
-                     base_D,
+                     pad_D,
                      nq,
                      sh.graph,
                      cfg.KBuild,
@@ -521,7 +533,7 @@ struct ggnn_handle {
       d_ids = r_ids.as<int32_t>();
       d_dists = r_dists.as<float>();
     }
-    BfLaunch bl{d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), base_D, nq, k_gt,
+    BfLaunch bl{d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
                 measure, d_ids, d_dists};
     EventTimer timer(stream);
     launch_bf_query(bl, stream);
@@ -739,6 +751,8 @@ ggnn_status ggnn_set_base(ggnn_t* h, const void* data, uint64_t N, uint32_t D, g
     }
     h->base_N = N;
     h->base_D = D;
+    const uint32_t epc = 16 / static_cast<uint32_t>(dtype_size(dtype));
+    h->pad_D = (D + epc - 1) / epc * epc;
     h->base_dtype = dtype;
     h->base_set = true;
   });
@@ -798,6 +812,7 @@ ggnn_status ggnn_get_graph(ggnn_t* h, uint32_t global_shard_id, ggnn_graph_view*
                  "Shard " + std::to_string(global_shard_id) + " does not exist.");
     const Shard& sh = h->shards[global_shard_id];
     out->config = h->cfg;
+    out->config.D = h->base_D;  // caller-visible dimension (rows are padded internally)
     out->graph = sh.graph;
     out->translation = sh.translation;
     out->selection = sh.selection;

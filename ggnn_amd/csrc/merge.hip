@@ -146,9 +146,11 @@ static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
   else if (args.sorted <= 128)
     hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.N_btm), dim3(kWave),
                        lds, stream, args);
+  else if (args.sorted <= 256)
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE>), dim3(args.N_btm), dim3(kWave),
+                       lds, stream, args);
   else
-    throw Error(GGNN_UNSUPPORTED,
-                "this build keeps the sorted cache in registers and supports KBuild <= 111");
+    throw Error(GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
 }
 
 void launch_merge(const MergeLaunch& a, hipStream_t stream)

@@ -110,9 +110,12 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   else if (sorted <= 128)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.Nq), dim3(kWave), lds,
                        stream, args);
+  else if (sorted <= 256)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE>), dim3(args.Nq), dim3(kWave), lds,
+                       stream, args);
   else
     throw Error(GGNN_UNSUPPORTED,
-                "this build keeps the sorted cache in registers and supports KQuery <= 111");
+                "this build keeps the sorted cache in registers and supports KQuery <= 239");
 }
 
 void launch_query(const QueryLaunch& a, hipStream_t stream)

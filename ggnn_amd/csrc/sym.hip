@@ -283,9 +283,11 @@ static void launch_sym_r(const SymArgs& args, hipStream_t stream)
   if (args.sorted <= 64)
     hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.count), dim3(kWave), lds,
                        stream, args);
+  else if (args.sorted <= 128)
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.count), dim3(kWave), lds,
+                       stream, args);
   else
-    throw Error(GGNN_UNSUPPORTED,
-                "this build keeps the sorted cache in registers and supports KBuild <= 97 in sym");
+    throw Error(GGNN_UNSUPPORTED, "KBuild too large for the sym cache");
 }
 
 void launch_sym(const SymLaunch& a, hipStream_t stream)

@@ -456,3 +456,63 @@ def test_bf_mfma_float_tolerance(ops, orc, measure):
     o_ids, o_d = orc.bf_query(base, q, 10, measure)
     np.testing.assert_allclose(d.cpu().numpy(), o_d, rtol=RTOL, atol=1e-7)
     assert (ids.cpu().numpy() == o_ids).mean() > 0.99
+
+
+# ---------------------------------------------------------------------------------------------
+# larger K: four sorted-list registers per lane (KQuery <= 239, KBuild up to the reference's
+# effective limit), and arbitrary D through zero-padded rows in the engine
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,iters", [(120, 512), (200, 512), (239, 1024)])
+def test_query_large_k_exact(ops, orc, small_graph, K, iters):
+    g = small_graph
+    q = make_int_data(24, g["D"], 91)
+    graph0 = g["graph"][:g["N"]]
+    ids, d = ops.query(dev(g["base"]), dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]),
+                       K, 0.8, iters)
+    o_ids, o_d = orc.query(g["base"], q, graph0, start_points(g), g["stats"], K, 0.8, iters)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
+
+
+def test_large_kbuild_merge_sym_exact(ops, orc):
+    N, D, K = 3000, 32, 120      # merge: sorted 160 (3 regs -> R=4), sym: sorted 96 (R=2)
+    base = make_int_data(N, D, 93)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, rng=orc.make_rng(N, 3))
+    d_base = dev(base)
+    gb, nn1 = ops.merge(d_base, cfg, dev(graph), dev(tr), dev(sel), dev(stats), 0.5, 3, 0)
+    o_gb, o_nn1 = orc.merge(base, cfg, graph, tr, sel, stats, 0.5, 3, 0)
+    assert np.array_equal(gb.cpu().numpy(), o_gb) and np.array_equal(nn1.cpu().numpy(), o_nn1)
+    KF, Nl = K // 2, 60
+    graph_l = graph[:N].copy()
+    sb = np.full((N, KF), -1, np.int32)
+    sa = np.zeros(N, np.uint32)
+    orc.margin_reset()
+    orc.sym(base, K, graph_l, None, stats, 0.5, sb, sa, first_n=0, count=Nl)
+    assert orc.margin_min() > 1e-5
+    d_sb = torch.full((N, KF), -1, dtype=torch.int32, device="cuda")
+    d_sa = torch.zeros(N, dtype=torch.int32, device="cuda")
+    d_graph, d_stats = dev(graph_l), dev(stats)
+    for n in range(Nl):
+        ops.sym(d_base, K, d_graph, None, d_stats, 0.5, d_sb, d_sa, first_n=n, count=1)
+    assert np.array_equal(d_sa.cpu().numpy().astype(np.uint32), sa)
+    assert np.array_equal(d_sb.cpu().numpy(), sb)
+
+
+@pytest.mark.parametrize("dtype,D", [("f32", 30), ("f32", 101), ("u8", 100), ("f32", 1)])
+def test_engine_pads_arbitrary_dimensions(orc, dtype, D):
+    import ggnn_amd as ggnn
+    N, K = 3000, 10
+    base, q = _data(dtype, N, D, 95), _data(dtype, 300, D, 96)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    gt, gd = eng.bf_query(q, K)
+    o_ids, o_d = orc.bf_query(base, q, K)
+    assert np.array_equal(gd.numpy(), o_d)
+    if D > 1:  # D=1 on 256 integer values is all ties at equal distances: ids still match
+        assert np.array_equal(gt.numpy(), o_ids)
+    eng.build(24, 0.5, 1)
+    ids, d = eng.query(q, K, 0.8, 400)
+    graph = eng.get_graph(0)
+    assert graph.config["D"] == D
+    o = orc.query(base, q, graph.graph[0].view.numpy(), graph.translation[3].view.numpy().reshape(-1),
+                  graph.nn1_stats.view.numpy().reshape(-1), K, 0.8, 400)
+    assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
