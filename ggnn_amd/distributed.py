@@ -77,11 +77,16 @@ class ShardedGGNN:
     def _exchange(self, ids, dists, k):
         P = self.world_size
         nq, stride = ids.shape
+        out_device = ids.device
+        if ids.is_cuda and dist.get_backend(self.group) == "gloo":
+            # backend without device collectives: stage the (small) candidate lists through the host
+            ids, dists = ids.cpu(), dists.cpu()
         # dim-0 concatenation layout (valid for RCCL and gloo): [P*Nq, stride] == [P, Nq, stride]
         g_ids = torch.empty((P * nq, stride), dtype=ids.dtype, device=ids.device)
         g_dists = torch.empty((P * nq, stride), dtype=dists.dtype, device=dists.device)
         dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
         dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=self.group)
+        g_ids, g_dists = g_ids.to(out_device), g_dists.to(out_device)
         return merge_gathered(g_ids.view(P, nq, stride), g_dists.view(P, nq, stride), k,
                               self.n_local)
 
