@@ -255,6 +255,11 @@ struct ggnn_handle {
     GGNN_REQUIRE(base_N < 0x7fffffffull, GGNN_INVALID_ARGUMENT,
                  "ids are int32: at most 2^31-1 base points per engine");
     graph_config_init(static_cast<uint32_t>(n), pad_D, KBuild, &cfg);
+    // every lower segment must be able to contribute its share of points to the layer above
+    // (the reference would silently select padding entries, wrs_select_layer.cu:57-66)
+    GGNN_REQUIRE(cfg.SG + (cfg.SG_off ? 1u : 0u) <= cfg.S0 && cfg.S0 >= 2, GGNN_INVALID_ARGUMENT,
+                 "shard too small for a 4-layer graph with this KBuild (need more points per "
+                 "bottom segment than are promoted to the next layer)");
     num_shards = static_cast<uint32_t>(spg);
     stage_base();
     shards.clear();

@@ -150,3 +150,73 @@ def test_misuse_after_build(data):
     e2.set_shard_size(1234)
     with pytest.raises(RuntimeError, match="evenly divisible"):
         e2.build(24, 0.5)
+
+
+def test_edge_cases_empty_and_tiny(orc):
+    import ggnn_amd as ggnn
+    base = make_int_data(3000, 32, 81)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.build(24, 0.5, 0)
+    ids, d = eng.query(np.zeros((0, 32), np.float32), 10, 0.5)       # empty query set
+    assert tuple(ids.shape) == (0, 10) and tuple(d.shape) == (0, 10)
+    ids, d = eng.bf_query(np.zeros((0, 32), np.float32), 5)
+    assert tuple(ids.shape) == (0, 5)
+    q1 = make_int_data(1, 32, 82)                                     # single query, k = 1
+    ids, d = eng.query(q1, 1, 0.5)
+    o = orc.bf_query(base, q1, 1)
+    assert tuple(ids.shape) == (1, 1) and d[0, 0] >= o[1][0, 0]
+    # N=100, K=8 -> G=2, S0=12 but 16 points per segment would have to be promoted
+    tiny = ggnn.GGNN()
+    tiny.set_base(make_int_data(100, 32, 83))
+    with pytest.raises(RuntimeError, match="too small"):
+        tiny.build(8, 0.5)
+    # N=100, K=24 -> G=1: a degenerate but valid hierarchy, as in the reference
+    ok = ggnn.GGNN()
+    ok.set_base(make_int_data(100, 32, 83))
+    ok.build(24, 0.5)
+    ids, d = ok.query(q1, 5, 0.9)
+    assert ids.numpy().min() >= 0 and ids.numpy().max() < 100
+    too_small = ggnn.GGNN()
+    too_small.set_base(make_int_data(20, 32, 83))
+    with pytest.raises(RuntimeError, match="too small"):
+        too_small.build(24, 0.5)
+
+
+@pytest.mark.parametrize("K", [2, 3, 8])
+def test_minimum_kbuild_build_and_query(orc, K):
+    import ggnn_amd as ggnn
+    base, q = make_int_data(4000, 32, 84), make_int_data(64, 32, 85)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.build(K, 0.5, 1)
+    g = eng.get_graph(0)
+    g0 = g.graph[0].view.numpy()
+    assert g0.shape == (4000, K) and g0.min() >= 0 and g0.max() < 4000
+    ids, d = eng.query(q, 5, 0.9, 400)
+    o = orc.query(base, q, g0, g.translation[3].view.numpy().reshape(-1),
+                  g.nn1_stats.view.numpy().reshape(-1), 5, 0.9, 400)
+    assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
+
+
+def test_duplicate_points_zero_distances(orc):
+    """every vector appears four times: zero distances, ties everywhere (merge's nn1 skips zero
+    distances, merge_layer.cu:147-157)"""
+    import ggnn_amd as ggnn
+    u = make_int_data(1000, 32, 86)
+    base = np.concatenate([u, u, u, u])
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.build(24, 0.5, 1)
+    g = eng.get_graph(0)
+    stats = g.nn1_stats.view.numpy().reshape(-1)
+    assert np.isfinite(stats).all() and stats[1] >= stats[0] >= 0
+    q = u[:50].copy()
+    ids, d = eng.query(q, 10, 0.8, 400)
+    gt, gd = eng.bf_query(q, 10)
+    o_gt, o_gd = orc.bf_query(base, q, 10)
+    assert np.array_equal(gt.numpy(), o_gt) and np.array_equal(gd.numpy(), o_gd)
+    assert (gd.numpy()[:, :4] == 0).all()
+    o = orc.query(base, q, g.graph[0].view.numpy(), g.translation[3].view.numpy().reshape(-1),
+                  stats, 10, 0.8, 400)
+    assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
