@@ -85,6 +85,60 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
   }
 }
 
+// Same kernel with the LDS-resident list (SORTED > 256, i.e. KQuery > 239).
+template <typename BaseT, int LPR, int NCH, int MODE>
+__global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  // [cache keys][sorted dists][ckeys 32 | cd0 32 | cd1 32]
+  int* keys = lds_raw;
+  float* dists = reinterpret_cast<float*>(lds_raw + a.cache);
+  const WaveLds lds(lds_raw + a.cache + a.sorted, 0);
+  const int lane = threadIdx.x;
+  const uint32_t n = blockIdx.x;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  const BaseT* query = static_cast<const BaseT*>(a.query);
+  const float nn1 = a.nn1_stats[1];
+  const float xi = (MODE == kL2) ? (nn1 * nn1) * a.tau * a.tau : nn1 * a.tau;
+  DistEngine<BaseT, LPR, NCH> de;
+  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+  LdsList sl;
+  sl.init(a.KQuery, a.sorted, a.cache, xi, keys, dists);
+  uint32_t cnt_dist = 0, cnt_pop = 0;
+  for (uint32_t i = 0; i < a.num_start; i += kKBlock) {
+    const int cand = (lane < (int)kKBlock && i + lane < a.num_start) ? a.start[i + lane]
+                                                                      : kEmptyKey;
+    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr);
+  }
+  for (uint32_t ite = 0; ite < a.max_iters; ++ite) {
+    __syncthreads();
+    const float d0 = sl.dist_at(0);
+    sl.xi = (MODE == kL2) ? fminf(xi, d0 * a.tau * a.tau) : fminf(xi, d0 * a.tau);
+    const int anchor = sl.pop(sl.criteria());
+    if (anchor == kEmptyKey)
+      break;
+    ++cnt_pop;
+    const int32_t* row = a.graph0 + static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild;
+    for (uint32_t i = 0; i < a.KBuild; i += kKBlock) {
+      const int cand = (lane < (int)kKBlock && i + lane < a.KBuild) ? row[i + lane] : kEmptyKey;
+      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr);
+    }
+  }
+  __syncthreads();
+  const size_t out_row = (static_cast<size_t>(n) * a.shards_per_gpu + a.on_gpu_shard) * a.KQuery;
+  const int32_t id_offset = static_cast<int32_t>(a.on_gpu_shard * a.N_base);
+  for (uint32_t i = lane; i < a.KQuery; i += kWave) {
+    a.ids[out_row + i] = keys[i] + id_offset;
+    a.dists[out_row + i] = dists[i];
+  }
+  if (lane == 0) {
+    if (a.n_dist)
+      a.n_dist[n] = cnt_dist;
+    if (a.n_pop)
+      a.n_pop[n] = cnt_pop;
+  }
+}
+
 void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_t* cache_size,
                   uint32_t* sorted_size)
 {
@@ -113,9 +167,13 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   else if (sorted <= 256)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE>), dim3(args.Nq), dim3(kWave), lds,
                        stream, args);
-  else
-    throw Error(GGNN_UNSUPPORTED,
-                "this build keeps the sorted cache in registers and supports KQuery <= 239");
+  else {
+    // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
+    const size_t lds_big = (args.cache + sorted + WaveLds::extra_ints) * sizeof(int);
+    GGNN_REQUIRE(lds_big <= 64 * 1024, GGNN_UNSUPPORTED, "cache too large for one workgroup");
+    hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE>), dim3(args.Nq), dim3(kWave),
+                       lds_big, stream, args);
+  }
 }
 
 void launch_query(const QueryLaunch& a, hipStream_t stream)

@@ -344,6 +344,135 @@ struct SortedList {
 };
 
 // ---------------------------------------------------------------------------------------------
+// LDS-resident form of the same cache for SORTED > 256 (KQuery up to 6000): a wave64 port of the
+// reference's physical layout and chunked shift-insert (simple_knn_cache.cuh:58-352, emulated
+// literally by oracle/ggnn_oracle.cpp::Cache with BLOCK = 64; the result does not depend on the
+// chunk width).  Slow path: every push walks the sorted region through LDS.
+// ---------------------------------------------------------------------------------------------
+struct LdsList {
+  int* key;     // [CACHE] physical layout: best | priority-queue ring | visited ring
+  float* dist;  // [SORTED]
+  int BEST, SORTED, CACHE;
+  int pq_head, vis_head, vis_count;
+  float xi;
+
+  GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* key_, float* dist_)
+  {
+    key = key_;
+    dist = dist_;
+    BEST = best;
+    SORTED = sorted;
+    CACHE = cache;
+    xi = xi_;
+    for (int i = threadIdx.x; i < CACHE; i += kWave) {
+      key[i] = kEmptyKey;
+      if (i < SORTED)
+        dist[i] = inf_f();
+    }
+    pq_head = BEST;
+    vis_head = SORTED;
+    vis_count = 0;
+    __syncthreads();
+  }
+  GGNN_DEV float dist_at(int i) const { return dist[i]; }
+  GGNN_DEV int key_at(int i) const { return key[i]; }
+  GGNN_DEV float criteria() const { return dist[BEST - 1] + xi; }
+
+  GGNN_DEV void push(int k, float d)
+  {
+    const int lane = threadIdx.x;
+    __syncthreads();
+    bool dup = false;
+    for (int i = lane; i < SORTED; i += kWave)
+      dup |= (key[i] == k);
+    if (__any(dup))
+      return;
+    const int head = pq_head;
+    const int head_in = head - BEST;
+    int r_key = kEmptyKey, idx = 0;
+    float r_dist = 0.f;
+    bool active = false;
+    int block_start = (SORTED + kWave - 1) / kWave * kWave;
+    for (;;) {
+      // shift (all lanes), then neighbour reads (all lanes), then inserts (all lanes)
+      if (active && r_key != kEmptyKey) {
+        const int idx_next = (idx + 1 == SORTED) ? BEST : idx + 1;
+        if (idx_next != BEST && idx_next != head) {  // Q1
+          key[idx_next] = r_key;
+          dist[idx_next] = r_dist;
+        }
+      }
+      __syncthreads();
+      bool ins = false;
+      if (active) {
+        const bool has_prev = idx != 0 && idx != head;
+        const int idx_prev = idx != BEST ? idx - 1 : SORTED - 1;
+        ins = !has_prev || dist[idx_prev] < d;
+      }
+      __syncthreads();
+      if (ins) {
+        key[idx] = k;
+        dist[idx] = d;
+      }
+      __syncthreads();
+      if (!block_start)
+        break;
+      block_start -= kWave;
+      const int li = block_start + lane;
+      active = li < SORTED;
+      if (active) {
+        idx = li;
+        if (li >= BEST)
+          idx = (li + head_in < SORTED) ? li + head_in : li + head_in - SORTED + BEST;
+        r_key = key[idx];
+        r_dist = dist[idx];
+        active = r_dist >= d;  // Q2
+      }
+      __syncthreads();
+    }
+  }
+
+  GGNN_DEV int pop(float crit)
+  {
+    __syncthreads();
+    const int k0 = key[pq_head];
+    const float d0 = dist[pq_head];
+    if (k0 == kEmptyKey || d0 >= crit)
+      return kEmptyKey;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      key[vis_head] = k0;
+      key[pq_head] = kEmptyKey;
+      dist[pq_head] = inf_f();
+    }
+    vis_head = (vis_head + 1 >= CACHE) ? SORTED : vis_head + 1;
+    vis_count = (vis_count + 1 > CACHE - SORTED) ? CACHE - SORTED : vis_count + 1;
+    pq_head = (pq_head + 1 >= SORTED) ? BEST : pq_head + 1;
+    __syncthreads();
+    return k0;
+  }
+
+  GGNN_DEV int filter(int cand, int* /*unused*/) const
+  {
+    const int lane = threadIdx.x;
+    __syncthreads();
+    const int E = SORTED + vis_count;  // the visited ring fills contiguously until it wraps
+    const int h = lane >> 5;
+    const int4* kp = reinterpret_cast<const int4*>(key);
+    unsigned acc = 0xffffffffu;
+    const unsigned c = static_cast<unsigned>(cand);
+    for (int t = 0; t * 8 < E; ++t) {
+      const int4 e = kp[t * 2 + h];
+      const unsigned a = min(static_cast<unsigned>(e.x) ^ c, static_cast<unsigned>(e.y) ^ c);
+      const unsigned b = min(static_cast<unsigned>(e.z) ^ c, static_cast<unsigned>(e.w) ^ c);
+      acc = min(acc, min(a, b));
+    }
+    const unsigned other = static_cast<unsigned>(__shfl_xor(static_cast<int>(acc), 32));
+    return (min(acc, other) == 0u) ? kEmptyKey : cand;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Distance engine.  Reference: Distance, include/ggnn/cuda_utils/distance.cuh:34-164 (squared
 // L2 / |1-cos|) and the two-point variant of simple_knn_sym_cache.cuh:143-283.
 // LPR lanes cooperate on one base row, each lane owns NCH chunks of 16 bytes.
@@ -555,8 +684,8 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
 
 // fetch(): simple_knn_cache.cuh:241-289.  cand: lane j (<32) holds candidate key j or EMPTY.
 // Returns the number of distance evaluations.
-template <int MODE, bool FILTER, int R, class DE>
-GGNN_DEV int fetch(SortedList<R>& sl, const DE& de, const WaveLds& lds, int cand,
+template <int MODE, bool FILTER, class SL, class DE>
+GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
                    const int32_t* translation)
 {
   const int lane = threadIdx.x;

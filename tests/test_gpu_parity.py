@@ -516,3 +516,18 @@ def test_engine_pads_arbitrary_dimensions(orc, dtype, D):
     o = orc.query(base, q, graph.graph[0].view.numpy(), graph.translation[3].view.numpy().reshape(-1),
                   graph.nn1_stats.view.numpy().reshape(-1), K, 0.8, 400)
     assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
+
+
+@pytest.mark.parametrize("K,iters", [(240, 400), (300, 512), (1000, 1024)])
+def test_query_lds_list_for_very_large_k(ops, orc, small_graph, K, iters):
+    """KQuery > 239: the sorted list lives in LDS (wave64 port of the literal shift-insert)."""
+    g = small_graph
+    q = make_int_data(12, g["D"], 97)
+    graph0 = g["graph"][:g["N"]]
+    ids, d, nd, npop = ops.query(dev(g["base"]), dev(q), dev(graph0), dev(start_points(g)),
+                                 dev(g["stats"]), K, 0.8, iters, counters=True)
+    o_ids, o_d, o_nd, o_np = orc.query(g["base"], q, graph0, start_points(g), g["stats"], K, 0.8,
+                                       iters, counters=True)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
+    assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
+    assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
