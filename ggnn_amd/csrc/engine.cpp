@@ -11,7 +11,9 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <exception>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -126,6 +128,48 @@ struct Shard {
 
 using namespace ggnn_amd;
 
+// everything one GPU owns (GPUInstance of the reference, gpu_instance.cuh:60-221, reduced to
+// resident shards)
+struct DeviceCtx {
+  int device{0};
+  hipStream_t stream{nullptr};
+  DeviceBuffer base_copy;       // this GPU's slice of the base unless it is borrowed
+  const void* d_base{nullptr};  // first row of the slice
+  uint32_t first_shard{0};      // global id of shards[0]
+  std::vector<Shard> shards;
+  float build_ms{0.f}, query_ms{0.f};
+  uint64_t n_dist{0}, n_pop{0};
+
+  DeviceCtx() = default;
+  DeviceCtx(const DeviceCtx&) = delete;
+  DeviceCtx& operator=(const DeviceCtx&) = delete;
+  DeviceCtx(DeviceCtx&& o) noexcept { *this = std::move(o); }
+  DeviceCtx& operator=(DeviceCtx&& o) noexcept
+  {
+    device = o.device;
+    stream = o.stream;
+    o.stream = nullptr;
+    base_copy = std::move(o.base_copy);
+    d_base = o.d_base;
+    first_shard = o.first_shard;
+    shards = std::move(o.shards);
+    return *this;
+  }
+  ~DeviceCtx()
+  {
+    if (stream) {
+      (void)hipSetDevice(device);
+      (void)hipStreamDestroy(stream);
+    }
+  }
+  void activate()
+  {
+    GGNN_HIP_CHECK(hipSetDevice(device));
+    if (!stream)
+      GGNN_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  }
+};
+
 struct ggnn_handle {
   // configuration (GGNNConfig, ggnn.cu:52-59)
   std::filesystem::path graph_dir{};
@@ -136,13 +180,12 @@ struct ggnn_handle {
   bool return_results_on_gpu{false};
   bool collect_counters{false};
 
-  // base
+  // base as handed over by the caller
   const void* base_src{nullptr};
   ggnn_location base_loc{GGNN_CPU};
   int base_gpu{0};
   std::vector<uint8_t> base_host_copy;
   DeviceBuffer base_dev_copy;
-  const void* d_base{nullptr};
   uint64_t base_N{0};
   uint32_t base_D{0};  // dimension as given by the caller
   uint32_t pad_D{0};   // row length the kernels see: rows are zero-padded to a multiple of 16 bytes
@@ -150,13 +193,11 @@ struct ggnn_handle {
   ggnn_dtype base_dtype{GGNN_F32};
   bool base_set{false};
 
-  // graph
+  // graph: one DeviceCtx per GPU, shards_per_gpu resident shards each
   bool prepared{false};
-  int device{0};
-  hipStream_t stream{nullptr};
   ggnn_graph_config cfg{};
-  uint32_t num_shards{0};
-  std::vector<Shard> shards;
+  uint32_t shards_per_gpu{0};
+  std::vector<DeviceCtx> devs;
 
   // tracing
   float build_ms{0.f}, query_ms{0.f}, bf_ms{0.f};
@@ -164,71 +205,81 @@ struct ggnn_handle {
 
   std::string last_error;
 
-  ~ggnn_handle()
+  size_t row_bytes() const { return static_cast<size_t>(pad_D) * dtype_size(base_dtype); }
+  uint32_t num_shards() const { return shards_per_gpu * static_cast<uint32_t>(devs.size()); }
+  bool has_graph() const
   {
-    if (stream)
-      (void)hipStreamDestroy(stream);
+    return prepared && !devs.empty() && !devs[0].shards.empty() && devs[0].shards[0].ready;
   }
 
-  void activate()
+  // runs f(ctx) for every GPU -- inline for one GPU, one host thread per GPU otherwise (the
+  // reference does the same, ggnn.cu:218-230,308-326); the first failure is rethrown
+  template <typename F>
+  void for_each_device(F&& f)
   {
-    GGNN_HIP_CHECK(hipSetDevice(device));
-    if (!stream)
-      GGNN_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  }
-
-  void select_device()
-  {
-    GGNN_REQUIRE(gpu_ids.size() <= 1, GGNN_UNSUPPORTED,
-                 "one engine drives one GPU; for several GPUs run one process per GPU "
-                 "(ggnn_amd.distributed.ShardedGGNN, RCCL all-gather of the candidates)");
-    if (gpu_ids.empty()) {
-      int d = 0;
-      GGNN_HIP_CHECK(hipGetDevice(&d));  // ggnn.cu:172-176
-      device = d;
-    }
-    else
-      device = gpu_ids[0];
-    activate();
-  }
-
-  // base.referenceOnGPU (dataset.cu:236-300): make the base resident on the engine's GPU
-  void stage_base()
-  {
-    if (d_base)
+    if (devs.size() == 1) {
+      devs[0].activate();
+      f(devs[0]);
       return;
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errors(devs.size());
+    for (size_t i = 0; i < devs.size(); ++i)
+      pool.emplace_back([&, i] {
+        try {
+          devs[i].activate();
+          f(devs[i]);
+        }
+        catch (...) {
+          errors[i] = std::current_exception();
+        }
+      });
+    for (auto& t : pool)
+      t.join();
+    for (auto& e : errors)
+      if (e)
+        std::rethrow_exception(e);
+  }
+
+  std::vector<int> resolve_gpus() const
+  {
+    if (!gpu_ids.empty())
+      return gpu_ids;
+    int d = 0;
+    GGNN_HIP_CHECK(hipGetDevice(&d));  // ggnn.cu:172-176
+    return {d};
+  }
+
+  // base.referenceOnGPU (dataset.cu:236-300): rows [row0, row0+rows) resident on ctx's GPU
+  void stage_base_slice(DeviceCtx& ctx, uint64_t row0, uint64_t rows)
+  {
     GGNN_REQUIRE(base_set, GGNN_INVALID_STATE, "The base needs to be set first.");
+    ctx.activate();
     const size_t es = dtype_size(base_dtype);
     const bool padded = pad_D != base_D;
-    const void* src = base_dev_copy.p ? base_dev_copy.p : base_src;
+    const uint8_t* src = static_cast<const uint8_t*>(base_src) + row0 * base_D * es;
     const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
-    if (!padded && aligned && base_loc == GGNN_GPU && base_gpu == device) {
-      d_base = src;  // device memory on the right GPU (borrowed or our own copy)
+    if (!padded && aligned && base_loc == GGNN_GPU && base_gpu == ctx.device) {
+      ctx.d_base = src;  // device memory on the right GPU (borrowed or our own copy)
       return;
     }
-    DeviceBuffer staged(base_N * pad_D * es);
-    const hipMemcpyKind kind =
-        base_loc == GGNN_GPU ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    ctx.base_copy.alloc(rows * pad_D * es);
+    const hipMemcpyKind kind = base_loc == GGNN_GPU ? hipMemcpyDefault : hipMemcpyHostToDevice;
     if (padded) {
-      GGNN_HIP_CHECK(hipMemsetAsync(staged.p, 0, staged.bytes, stream));
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(staged.p, pad_D * es, src, base_D * es, base_D * es, base_N,
-                                      kind, stream));
+      GGNN_HIP_CHECK(hipMemsetAsync(ctx.base_copy.p, 0, ctx.base_copy.bytes, ctx.stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(ctx.base_copy.p, pad_D * es, src, base_D * es, base_D * es,
+                                      rows, kind, ctx.stream));
     }
     else
-      GGNN_HIP_CHECK(hipMemcpyAsync(staged.p, src, staged.bytes, kind, stream));
-    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
-    base_dev_copy = std::move(staged);
-    base_gpu = device;
-    base_loc = GGNN_GPU;
-    base_host_copy.clear();
-    base_host_copy.shrink_to_fit();
-    d_base = base_dev_copy.p;
+      GGNN_HIP_CHECK(hipMemcpyAsync(ctx.base_copy.p, src, ctx.base_copy.bytes, kind, ctx.stream));
+    GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    ctx.d_base = ctx.base_copy.p;
   }
 
-  const void* shard_base(uint32_t shard) const
+  const void* shard_base(const DeviceCtx& ctx, uint32_t local_shard) const
   {
-    return static_cast<const uint8_t*>(d_base) +
-           static_cast<size_t>(shard) * cfg.N * pad_D * dtype_size(base_dtype);
+    return static_cast<const uint8_t*>(ctx.d_base) +
+           static_cast<size_t>(local_shard) * cfg.N * row_bytes();
   }
 
   // GGNNImpl::prepare, ggnn.cu:154-203
@@ -248,47 +299,63 @@ struct ggnn_handle {
     GGNN_REQUIRE(base_D >= 1 && base_D <= 4096, GGNN_INVALID_ARGUMENT, "D must be in [1, 4096]");
     GGNN_REQUIRE(KBuild >= 2 && KBuild <= 512, GGNN_INVALID_ARGUMENT,
                  "KBuild must be in [2, 512]");
-    select_device();
-    const uint64_t spg = base_N / n;  // one GPU: shards per GPU = all shards
-    GGNN_REQUIRE(n * spg == base_N, GGNN_INVALID_ARGUMENT,
+    const std::vector<int> gpus = resolve_gpus();
+    const uint64_t num_gpus = gpus.size();
+    const uint64_t spg = base_N / (n * num_gpus);
+    GGNN_REQUIRE(n * num_gpus * spg == base_N && spg > 0, GGNN_INVALID_ARGUMENT,
                  "base.N needs to be evenly divisible by (N_shard x num_gpus).");
     GGNN_REQUIRE(base_N < 0x7fffffffull, GGNN_INVALID_ARGUMENT,
-                 "ids are int32: at most 2^31-1 base points per engine");
+                 "ids are int32: at most 2^31-1 base points");
     graph_config_init(static_cast<uint32_t>(n), pad_D, KBuild, &cfg);
     // every lower segment must be able to contribute its share of points to the layer above
     // (the reference would silently select padding entries, wrs_select_layer.cu:57-66)
     GGNN_REQUIRE(cfg.SG + (cfg.SG_off ? 1u : 0u) <= cfg.S0 && cfg.S0 >= 2, GGNN_INVALID_ARGUMENT,
                  "shard too small for a 4-layer graph with this KBuild (need more points per "
                  "bottom segment than are promoted to the next layer)");
-    num_shards = static_cast<uint32_t>(spg);
-    stage_base();
-    shards.clear();
-    shards.resize(num_shards);
-    for (uint32_t i = 0; i < num_shards; ++i) {
-      shards[i].global_id = i;
-      shards[i].allocate(cfg);
+    shards_per_gpu = static_cast<uint32_t>(spg);
+    // reuse a context created by an earlier bf_query() when it fits
+    const bool reuse = devs.size() == 1 && num_gpus == 1 && devs[0].device == gpus[0];
+    if (!reuse) {
+      devs.clear();
+      devs.resize(num_gpus);
+    }
+    for (uint32_t i = 0; i < num_gpus; ++i) {
+      DeviceCtx& ctx = devs[i];
+      ctx.device = gpus[i];
+      ctx.first_shard = i * shards_per_gpu;
+      ctx.activate();
+      if (!reuse)
+        stage_base_slice(ctx, static_cast<uint64_t>(ctx.first_shard) * n,
+                         static_cast<uint64_t>(shards_per_gpu) * n);
+      ctx.shards.clear();
+      ctx.shards.resize(shards_per_gpu);
+      for (uint32_t s = 0; s < shards_per_gpu; ++s) {
+        ctx.shards[s].global_id = ctx.first_shard + s;
+        ctx.shards[s].allocate(cfg);
+      }
     }
     prepared = true;
-    GGNN_LOG(1, "prepare: N_shard=%u shards=%u D=%u K=%u G=%u S=%u S0=%u S0_off=%u N_all=%u",
-             cfg.N, num_shards, cfg.D, cfg.KBuild, cfg.G, cfg.S, cfg.S0, cfg.S0_off, cfg.N_all);
+    GGNN_LOG(1, "prepare: gpus=%zu N_shard=%u shards/gpu=%u D=%u K=%u G=%u S=%u S0=%u S0_off=%u",
+             devs.size(), cfg.N, shards_per_gpu, cfg.D, cfg.KBuild, cfg.G, cfg.S, cfg.S0,
+             cfg.S0_off);
   }
 
-  // GraphConstructionImpl::build / refine, graph_construction.cu:128-147
-  void build(uint32_t KBuild, float tau_build, uint32_t refinement_iterations,
-             ggnn_measure measure)
+  // GraphConstructionImpl::build / refine, graph_construction.cu:128-147, for all shards of ctx
+  void build_device(DeviceCtx& ctx, float tau_build, uint32_t refinement_iterations,
+                    ggnn_measure measure)
   {
-    prepare(KBuild);
     const uint32_t N = cfg.N, K = cfg.KBuild, KF = cfg.KF;
+    hipStream_t stream = ctx.stream;
     // scratch (GraphBuffer, graph_buffer.cu:38-81); not overlapped -- HBM is plentiful
     DeviceBuffer nn1_dist(static_cast<size_t>(N) * 4), graph_buffer(static_cast<size_t>(N) * K * 4),
         rng(static_cast<size_t>(N) * 4), sym_buffer(static_cast<size_t>(N) * KF * 4),
         sym_atomic(static_cast<size_t>(N) * 4), stats_scratch(2 * kStatsBlocks * 4);
-    build_ms = 0.f;
-    uint64_t rng_calls = 0;
+    ctx.build_ms = 0.f;
+    uint64_t rng_calls = static_cast<uint64_t>(ctx.first_shard) << 16;
 
-    for (uint32_t si = 0; si < num_shards; ++si) {
-      Shard& sh = shards[si];
-      const void* base = shard_base(si);
+    for (uint32_t si = 0; si < ctx.shards.size(); ++si) {
+      Shard& sh = ctx.shards[si];
+      const void* base = shard_base(ctx, si);
       EventTimer timer(stream);
 
       auto layer_graph = [&](uint32_t l) {
@@ -377,93 +444,98 @@ struct ggnn_handle {
         }
       }
       const float ms = timer.stop();
-      build_ms += ms;
+      ctx.build_ms += ms;
       sh.ready = true;
-      GGNN_LOG(0, "build(): part %u => %.3f s [%u points -> %.3f us/point]", si, ms / 1000.f, N,
-               ms * 1000.f / static_cast<float>(N));
+      GGNN_LOG(0, "[GPU: %d] build(): part %u => %.3f s [%u points -> %.3f us/point]", ctx.device,
+               sh.global_id, ms / 1000.f, N, ms * 1000.f / static_cast<float>(N));
     }
     GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  void build(uint32_t KBuild, float tau_build, uint32_t refinement_iterations,
+             ggnn_measure measure)
+  {
+    prepare(KBuild);
+    for_each_device(
+        [&](DeviceCtx& ctx) { build_device(ctx, tau_build, refinement_iterations, measure); });
+    build_ms = 0.f;
+    for (const DeviceCtx& ctx : devs)
+      build_ms += ctx.build_ms;  // "Sum of shard build times", ggnn.cu:237
+    release_caller_copy();
+  }
+
+  // the engine's own host/device copy of the caller's base is no longer needed once every GPU
+  // holds its slice
+  void release_caller_copy()
+  {
+    bool borrowed_from_copy = false;
+    for (const DeviceCtx& ctx : devs)
+      borrowed_from_copy |= (ctx.base_copy.p == nullptr);
+    base_host_copy.clear();
+    base_host_copy.shrink_to_fit();
+    if (!borrowed_from_copy)
+      base_dev_copy.release();
   }
 
   struct Staged {
     const void* ptr{nullptr};
     DeviceBuffer owned;
   };
-  Staged stage_query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc)
+  void check_query(uint64_t Nq, uint32_t D, ggnn_dtype dtype, const void* q) const
   {
     GGNN_REQUIRE(dtype == base_dtype, GGNN_INVALID_ARGUMENT,
                  "query data type does not match base data type");
     GGNN_REQUIRE(D == base_D, GGNN_INVALID_ARGUMENT, "query dimension does not match the base");
     GGNN_REQUIRE(Nq < 0xffffffffull, GGNN_INVALID_ARGUMENT, "too many queries");
+    GGNN_REQUIRE(!Nq || q != nullptr, GGNN_INVALID_ARGUMENT, "query pointer is null");
+  }
+  // query.referenceOnGPU (gpu_instance.cu:638-641): the full query set on ctx's GPU
+  Staged stage_query(DeviceCtx& ctx, const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
+                     ggnn_location loc, int q_gpu)
+  {
     Staged s;
     if (!Nq)
       return s;
-    GGNN_REQUIRE(q != nullptr, GGNN_INVALID_ARGUMENT, "query pointer is null");
     const size_t es = dtype_size(dtype);
     const bool padded = pad_D != base_D;
-    if (loc == GGNN_GPU && !padded && (reinterpret_cast<uintptr_t>(q) & 15u) == 0) {
+    if (loc == GGNN_GPU && q_gpu == ctx.device && !padded &&
+        (reinterpret_cast<uintptr_t>(q) & 15u) == 0) {
       s.ptr = q;
       return s;
     }
-    const hipMemcpyKind kind = loc == GGNN_GPU ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind kind = loc == GGNN_GPU ? hipMemcpyDefault : hipMemcpyHostToDevice;
     s.owned.alloc(Nq * pad_D * es);
     if (padded) {
-      GGNN_HIP_CHECK(hipMemsetAsync(s.owned.p, 0, s.owned.bytes, stream));
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(s.owned.p, pad_D * es, q, D * es, D * es, Nq, kind, stream));
+      GGNN_HIP_CHECK(hipMemsetAsync(s.owned.p, 0, s.owned.bytes, ctx.stream));
+      GGNN_HIP_CHECK(
+          hipMemcpy2DAsync(s.owned.p, pad_D * es, q, D * es, D * es, Nq, kind, ctx.stream));
     }
     else
-      GGNN_HIP_CHECK(hipMemcpyAsync(s.owned.p, q, s.owned.bytes, kind, stream));
+      GGNN_HIP_CHECK(hipMemcpyAsync(s.owned.p, q, s.owned.bytes, kind, ctx.stream));
     s.ptr = s.owned.p;
     return s;
   }
 
-  void copy_out(const void* d_src, void* dst, size_t bytes, ggnn_location loc)
+  // GPUInstance::query, gpu_instance.cu:626-743: all shards of one GPU into d_ids/d_dists
+  // [Nq, K * shards_per_gpu]
+  void query_device(DeviceCtx& ctx, const void* d_query, uint32_t nq, uint32_t k_query,
+                    float tau_query, uint32_t max_iterations, ggnn_measure measure,
+                    int32_t* d_ids, float* d_dists)
   {
-    if (!bytes)
-      return;
-    GGNN_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes,
-                                  loc == GGNN_GPU ? hipMemcpyDeviceToDevice
-                                                  : hipMemcpyDeviceToHost,
-                                  stream));
-  }
-
-  // GGNNImpl::queryImpl + GPUInstance::query, ggnn.cu:278-330, gpu_instance.cu:626-743
-  void query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
-             uint32_t k_query, float tau_query, uint32_t max_iterations, ggnn_measure measure,
-             int32_t* ids_out, float* dists_out, ggnn_location out_loc)
-  {
-    GGNN_REQUIRE(prepared && !shards.empty() && shards[0].ready, GGNN_INVALID_STATE,
-                 "There is no graph to query.");
-    activate();
-    Staged sq = stage_query(q, Nq, D, dtype, loc);
-    query_ms = 0.f;
-    last_n_dist = last_n_pop = 0;
-    if (!Nq)
-      return;
-    const uint32_t nq = static_cast<uint32_t>(Nq);
-    const size_t row = static_cast<size_t>(k_query) * num_shards;
-    // results [Nq, K*shards] (gpu_instance.cu:643-645); written straight into the caller's
-    // device buffer when that is what was asked for
-    const bool direct = (out_loc == GGNN_GPU);
-    DeviceBuffer r_ids, r_dists;
-    int32_t* d_ids = ids_out;
-    float* d_dists = dists_out;
-    if (!direct) {
-      r_ids.alloc(nq * row * 4);
-      r_dists.alloc(nq * row * 4);
-      d_ids = r_ids.as<int32_t>();
-      d_dists = r_dists.as<float>();
-    }
+    hipStream_t stream = ctx.stream;
+    const uint32_t spg = shards_per_gpu;
     DeviceBuffer c_dist, c_pop;
     if (collect_counters) {
       c_dist.alloc(static_cast<size_t>(nq) * 4);
       c_pop.alloc(static_cast<size_t>(nq) * 4);
     }
+    ctx.query_ms = 0.f;
+    ctx.n_dist = ctx.n_pop = 0;
     std::vector<uint32_t> h_cnt;
-    for (uint32_t si = 0; si < num_shards; ++si) {
-      const Shard& sh = shards[si];
-      QueryLaunch ql{shard_base(si),
-                     sq.ptr,
+    for (uint32_t si = 0; si < spg; ++si) {
+      const Shard& sh = ctx.shards[si];
+      QueryLaunch ql{shard_base(ctx, si),
+                     d_query,
                      base_dtype,
                      cfg.N,
                      pad_D,
@@ -477,7 +549,7 @@ struct ggnn_handle {
                      tau_query,
                      max_iterations,
                      measure,
-                     num_shards,
+                     spg,
                      si,
                      d_ids,
                      d_dists,
@@ -486,47 +558,117 @@ struct ggnn_handle {
       EventTimer timer(stream);
       launch_query(ql, stream);
       const float ms = timer.stop();
-      query_ms += ms;
-      GGNN_LOG(0, "query part %u => ms: %.3f [%u points query -> %.3f us/point]", si, ms, nq,
-               ms * 1000.f / static_cast<float>(nq));
+      ctx.query_ms += ms;
+      GGNN_LOG(0, "[GPU: %d] query part %u => ms: %.3f [%u points query -> %.3f us/point]",
+               ctx.device, sh.global_id, ms, nq, ms * 1000.f / static_cast<float>(nq));
       if (collect_counters) {
         h_cnt.resize(nq);
         GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_dist.p, nq * 4ull, hipMemcpyDeviceToHost));
         for (uint32_t v : h_cnt)
-          last_n_dist += v;
+          ctx.n_dist += v;
         GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_pop.p, nq * 4ull, hipMemcpyDeviceToHost));
         for (uint32_t v : h_cnt)
-          last_n_pop += v;
+          ctx.n_pop += v;
       }
     }
-    if (num_shards > 1)
-      launch_sort_shard_results(nq, static_cast<uint32_t>(row), d_ids, d_dists, stream);
-    if (!direct) {
-      // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, d_ids, row * 4, k_query * 4ull, nq,
-                                      hipMemcpyDeviceToHost, stream));
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, d_dists, row * 4, k_query * 4ull,
-                                      nq, hipMemcpyDeviceToHost, stream));
-    }
+    if (spg > 1)
+      launch_sort_shard_results(nq, k_query * spg, d_ids, d_dists, stream);
     GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+
+  // GGNNImpl::queryImpl, ggnn.cu:278-330
+  void query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
+             int q_gpu, uint32_t k_query, float tau_query, uint32_t max_iterations,
+             ggnn_measure measure, int32_t* ids_out, float* dists_out, ggnn_location out_loc)
+  {
+    GGNN_REQUIRE(has_graph(), GGNN_INVALID_STATE, "There is no graph to query.");
+    check_query(Nq, D, dtype, q);
+    const bool direct = (out_loc == GGNN_GPU);
+    GGNN_REQUIRE(!(direct && devs.size() > 1), GGNN_INVALID_STATE,
+                 "Returning query results on GPU is only possible when using a single GPU.");
+    query_ms = 0.f;
+    last_n_dist = last_n_pop = 0;
+    if (!Nq)
+      return;
+    const uint32_t nq = static_cast<uint32_t>(Nq);
+    const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
+    std::vector<DeviceBuffer> r_ids(devs.size()), r_dists(devs.size());
+
+    for_each_device([&](DeviceCtx& ctx) {
+      const size_t i = static_cast<size_t>(&ctx - devs.data());
+      Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
+      int32_t* d_ids = ids_out;
+      float* d_dists = dists_out;
+      if (!direct) {
+        r_ids[i].alloc(nq * row * 4);
+        r_dists[i].alloc(nq * row * 4);
+        d_ids = r_ids[i].as<int32_t>();
+        d_dists = r_dists[i].as<float>();
+      }
+      query_device(ctx, sq.ptr, nq, k_query, tau_query, max_iterations, measure, d_ids, d_dists);
+    });
+    for (const DeviceCtx& ctx : devs) {
+      query_ms = std::max(query_ms, ctx.query_ms);  // GPUs run concurrently
+      last_n_dist += ctx.n_dist;
+      last_n_pop += ctx.n_pop;
+    }
+    if (direct)
+      return;
+
+    DeviceCtx& d0 = devs[0];
+    d0.activate();
+    if (devs.size() == 1) {
+      // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, r_ids[0].p, row * 4, k_query * 4ull,
+                                      nq, hipMemcpyDeviceToHost, d0.stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, r_dists[0].p, row * 4,
+                                      k_query * 4ull, nq, hipMemcpyDeviceToHost, d0.stream));
+      GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
+      return;
+    }
+    // several GPUs: candidates to the first GPU (peer copies over xGMI), k-way merge there with
+    // id offset g * shards_per_gpu * N_shard (result_merger.cpp:115-116)
+    const size_t part = nq * row;
+    DeviceBuffer g_ids(devs.size() * part * 4), g_dists(devs.size() * part * 4), m_ids(nq * k_query * 4ull),
+        m_dists(nq * k_query * 4ull);
+    for (size_t g = 0; g < devs.size(); ++g) {
+      GGNN_HIP_CHECK(hipMemcpyAsync(g_ids.as<int32_t>() + g * part, r_ids[g].p, part * 4,
+                                    hipMemcpyDefault, d0.stream));
+      GGNN_HIP_CHECK(hipMemcpyAsync(g_dists.as<float>() + g * part, r_dists[g].p, part * 4,
+                                    hipMemcpyDefault, d0.stream));
+    }
+    launch_merge_results(nq, k_query, static_cast<uint32_t>(devs.size()),
+                         static_cast<uint32_t>(row), shards_per_gpu * cfg.N, g_ids.as<int32_t>(),
+                         g_dists.as<float>(), m_ids.as<int32_t>(), m_dists.as<float>(), d0.stream);
+    GGNN_HIP_CHECK(hipMemcpyAsync(ids_out, m_ids.p, m_ids.bytes, hipMemcpyDeviceToHost, d0.stream));
+    GGNN_HIP_CHECK(
+        hipMemcpyAsync(dists_out, m_dists.p, m_dists.bytes, hipMemcpyDeviceToHost, d0.stream));
+    GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
   }
 
   // GGNNImpl::bfQueryImpl, ggnn.cu:332-390
   void bf_query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
-                uint32_t k_gt, ggnn_measure measure, int32_t* ids_out, float* dists_out,
-                ggnn_location out_loc)
+                int q_gpu, uint32_t k_gt, ggnn_measure measure, int32_t* ids_out,
+                float* dists_out, ggnn_location out_loc)
   {
     GGNN_REQUIRE(base_set, GGNN_INVALID_STATE,
                  "There is no base dataset loaded which could be queried.");
-    if (!prepared)
-      select_device();
-    else
-      activate();
-    stage_base();
-    Staged sq = stage_query(q, Nq, D, dtype, loc);
+    GGNN_REQUIRE(devs.size() <= 1, GGNN_INVALID_STATE,
+                 "The brute-force query only supports a single GPU.");
+    check_query(Nq, D, dtype, q);
+    if (devs.empty()) {
+      // no graph yet: make the whole base resident on the (first) selected GPU
+      const std::vector<int> gpus = resolve_gpus();
+      devs.resize(1);
+      devs[0].device = gpus[0];
+      stage_base_slice(devs[0], 0, base_N);
+    }
+    DeviceCtx& ctx = devs[0];
+    ctx.activate();
     bf_ms = 0.f;
     if (!Nq)
       return;
+    Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
     const uint32_t nq = static_cast<uint32_t>(Nq);
     const bool direct = (out_loc == GGNN_GPU);
     DeviceBuffer r_ids, r_dists;
@@ -538,18 +680,20 @@ struct ggnn_handle {
       d_ids = r_ids.as<int32_t>();
       d_dists = r_dists.as<float>();
     }
-    BfLaunch bl{d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
-                measure, d_ids, d_dists};
-    EventTimer timer(stream);
-    launch_bf_query(bl, stream);
+    BfLaunch bl{ctx.d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
+                measure,    d_ids,  d_dists};
+    EventTimer timer(ctx.stream);
+    launch_bf_query(bl, ctx.stream);
     bf_ms = timer.stop();
-    GGNN_LOG(0, "brute-force query: => ms: %.3f [%u points query -> %.3f us/point]", bf_ms, nq,
-             bf_ms * 1000.f / static_cast<float>(nq));
+    GGNN_LOG(0, "[GPU: %d] brute-force query: => ms: %.3f [%u points query -> %.3f us/point]",
+             ctx.device, bf_ms, nq, bf_ms * 1000.f / static_cast<float>(nq));
     if (!direct) {
-      copy_out(d_ids, ids_out, static_cast<size_t>(nq) * k_gt * 4, out_loc);
-      copy_out(d_dists, dists_out, static_cast<size_t>(nq) * k_gt * 4, out_loc);
+      GGNN_HIP_CHECK(hipMemcpyAsync(ids_out, d_ids, static_cast<size_t>(nq) * k_gt * 4,
+                                    hipMemcpyDeviceToHost, ctx.stream));
+      GGNN_HIP_CHECK(hipMemcpyAsync(dists_out, d_dists, static_cast<size_t>(nq) * k_gt * 4,
+                                    hipMemcpyDeviceToHost, ctx.stream));
     }
-    GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+    GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
   }
 
   std::filesystem::path part_file(uint32_t shard) const
@@ -560,19 +704,20 @@ struct ggnn_handle {
 
   void store()
   {
-    GGNN_REQUIRE(prepared && !shards.empty() && shards[0].ready, GGNN_INVALID_STATE,
-                 "There is no graph to store.");
-    activate();
+    GGNN_REQUIRE(has_graph(), GGNN_INVALID_STATE, "There is no graph to store.");
     if (graph_dir.empty())
       graph_dir = std::filesystem::current_path();
-    std::vector<char> host(Shard::pool_bytes(cfg));
-    for (const Shard& sh : shards) {
-      GGNN_HIP_CHECK(hipMemcpy(host.data(), sh.pool.p, host.size(), hipMemcpyDeviceToHost));
-      std::ofstream f(part_file(sh.global_id), std::ios::binary | std::ios::trunc);
-      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "cannot open " + part_file(sh.global_id).string());
-      f.write(host.data(), static_cast<std::streamsize>(host.size()));
-      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short write to " + part_file(sh.global_id).string());
-    }
+    for_each_device([&](DeviceCtx& ctx) {
+      std::vector<char> host(Shard::pool_bytes(cfg));
+      for (const Shard& sh : ctx.shards) {
+        GGNN_HIP_CHECK(hipMemcpy(host.data(), sh.pool.p, host.size(), hipMemcpyDeviceToHost));
+        std::ofstream f(part_file(sh.global_id), std::ios::binary | std::ios::trunc);
+        GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "cannot open " + part_file(sh.global_id).string());
+        f.write(host.data(), static_cast<std::streamsize>(host.size()));
+        GGNN_REQUIRE(f.good(), GGNN_IO_ERROR,
+                     "short write to " + part_file(sh.global_id).string());
+      }
+    });
   }
 
   void load(uint32_t KBuild)
@@ -582,20 +727,23 @@ struct ggnn_handle {
     if (graph_dir.empty())
       graph_dir = std::filesystem::current_path();
     prepare(KBuild);
-    std::vector<char> host(Shard::pool_bytes(cfg));
-    for (Shard& sh : shards) {
-      const auto file = part_file(sh.global_id);
-      std::error_code ec;
-      const auto sz = std::filesystem::file_size(file, ec);
-      // the reference validates by file size only (gpu_instance.cu:413-415)
-      GGNN_REQUIRE(!ec && sz == host.size(), GGNN_IO_ERROR,
-                   "missing or mismatching graph file " + file.string());
-      std::ifstream f(file, std::ios::binary);
-      f.read(host.data(), static_cast<std::streamsize>(host.size()));
-      GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short read from " + file.string());
-      GGNN_HIP_CHECK(hipMemcpy(sh.pool.p, host.data(), host.size(), hipMemcpyHostToDevice));
-      sh.ready = true;
-    }
+    for_each_device([&](DeviceCtx& ctx) {
+      std::vector<char> host(Shard::pool_bytes(cfg));
+      for (Shard& sh : ctx.shards) {
+        const auto file = part_file(sh.global_id);
+        std::error_code ec;
+        const auto sz = std::filesystem::file_size(file, ec);
+        // the reference validates by file size only (gpu_instance.cu:413-415)
+        GGNN_REQUIRE(!ec && sz == host.size(), GGNN_IO_ERROR,
+                     "missing or mismatching graph file " + file.string());
+        std::ifstream f(file, std::ios::binary);
+        f.read(host.data(), static_cast<std::streamsize>(host.size()));
+        GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short read from " + file.string());
+        GGNN_HIP_CHECK(hipMemcpy(sh.pool.p, host.data(), host.size(), hipMemcpyHostToDevice));
+        sh.ready = true;
+      }
+    });
+    release_caller_copy();
   }
 };
 
@@ -737,7 +885,7 @@ ggnn_status ggnn_set_base(ggnn_t* h, const void* data, uint64_t N, uint32_t D, g
     const size_t bytes = N * D * dtype_size(dtype);
     h->base_host_copy.clear();
     h->base_dev_copy.release();
-    h->d_base = nullptr;
+    h->devs.clear();  // a base staged for an earlier bf_query() is stale now
     h->base_src = data;
     h->base_loc = location;
     h->base_gpu = gpu_id;
@@ -783,25 +931,26 @@ ggnn_status ggnn_load(ggnn_t* h, uint32_t k_build)
 }
 
 ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
-                       ggnn_location location, int /*gpu_id*/, uint32_t k_query, float tau_query,
+                       ggnn_location location, int gpu_id, uint32_t k_query, float tau_query,
                        uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
                        float* dists_out, ggnn_location out_location)
 {
   GGNN_NEED_HANDLE(h);
   return guarded(h, [&] {
-    h->query(query, Nq, D, dtype, location, k_query, tau_query, max_iterations, measure, ids_out,
-             dists_out, out_location);
+    h->query(query, Nq, D, dtype, location, gpu_id, k_query, tau_query, max_iterations, measure,
+             ids_out, dists_out, out_location);
   });
 }
 
 ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
-                          ggnn_dtype dtype, ggnn_location location, int /*gpu_id*/,
+                          ggnn_dtype dtype, ggnn_location location, int gpu_id,
                           uint32_t k_gt, ggnn_measure measure, int32_t* ids_out, float* dists_out,
                           ggnn_location out_location)
 {
   GGNN_NEED_HANDLE(h);
   return guarded(h, [&] {
-    h->bf_query(query, Nq, D, dtype, location, k_gt, measure, ids_out, dists_out, out_location);
+    h->bf_query(query, Nq, D, dtype, location, gpu_id, k_gt, measure, ids_out, dists_out,
+                out_location);
   });
 }
 
@@ -811,18 +960,18 @@ ggnn_status ggnn_get_graph(ggnn_t* h, uint32_t global_shard_id, ggnn_graph_view*
   return guarded(h, [&] {
     GGNN_REQUIRE(out != nullptr, GGNN_INVALID_ARGUMENT, "null output");
     // ggnn.cu:392-413
-    GGNN_REQUIRE(h->prepared && !h->shards.empty() && h->shards[0].ready, GGNN_INVALID_STATE,
-                 "No graph has been built or loaded yet.");
-    GGNN_REQUIRE(global_shard_id < h->num_shards, GGNN_INVALID_STATE,
+    GGNN_REQUIRE(h->has_graph(), GGNN_INVALID_STATE, "No graph has been built or loaded yet.");
+    GGNN_REQUIRE(global_shard_id < h->num_shards(), GGNN_INVALID_STATE,
                  "Shard " + std::to_string(global_shard_id) + " does not exist.");
-    const Shard& sh = h->shards[global_shard_id];
+    const DeviceCtx& ctx = h->devs[global_shard_id / h->shards_per_gpu];
+    const Shard& sh = ctx.shards[global_shard_id % h->shards_per_gpu];
     out->config = h->cfg;
     out->config.D = h->base_D;  // caller-visible dimension (rows are padded internally)
     out->graph = sh.graph;
     out->translation = sh.translation;
     out->selection = sh.selection;
     out->nn1_stats = sh.nn1_stats;
-    out->gpu_id = h->device;
+    out->gpu_id = ctx.device;
   });
 }
 

@@ -220,3 +220,54 @@ def test_duplicate_points_zero_distances(orc):
     o = orc.query(base, q, g.graph[0].view.numpy(), g.translation[3].view.numpy().reshape(-1),
                   stats, 10, 0.8, 400)
     assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
+
+
+@pytest.mark.parametrize("shard_size", [4000, 2000])
+def test_in_process_multi_gpu(orc, shard_size):
+    """set_gpus([...]) with several entries drives several device contexts from one handle (host
+    thread per GPU, candidates copied to the first GPU, device merge) like the reference's
+    ggnn_main_multi_gpu example.  The test box has one GPU, so both contexts use device 0."""
+    import ggnn_amd as ggnn
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 87), make_int_data(120, D, 88)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_gpus([0, 0])
+    with pytest.raises(RuntimeError, match="evenly divisible"):
+        eng.build(24, 0.5, 1)      # as in the reference, several GPUs need an explicit shard size
+    eng.set_shard_size(shard_size)
+    eng.build(24, 0.5, 1)
+    ids, d = eng.query(q, K, 0.7, 400)
+    assert tuple(ids.shape) == (120, K) and not ids.is_cuda
+    n_shard = shard_size
+    spg = N // n_shard // 2
+    # reference semantics: per-GPU sorted rows, then ResultMerger with offset g*spg*N_shard
+    parts_i, parts_d = [], []
+    for gpu in range(2):
+        rows_i, rows_d = [], []
+        for s in range(spg):
+            gs = gpu * spg + s
+            g = eng.get_graph(gs)
+            lo = gs * n_shard
+            o = orc.query(base[lo:lo + n_shard], q, g.graph[0].view.numpy(),
+                          g.translation[3].view.numpy().reshape(-1),
+                          g.nn1_stats.view.numpy().reshape(-1), K, 0.7, 400)
+            rows_i.append(o[0] + s * n_shard)
+            rows_d.append(o[1])
+        si, sd = orc.sort_shard_results(np.concatenate(rows_i, 1), np.concatenate(rows_d, 1))
+        parts_i.append(si)
+        parts_d.append(sd)
+    r_ids, r_d = orc.merge_results(parts_i, parts_d, K, spg, n_shard)
+    assert np.array_equal(d.numpy(), r_d)
+    uniq = np.ones_like(r_d, bool)
+    uniq[:, 1:] &= r_d[:, 1:] != r_d[:, :-1]
+    uniq[:, :-1] &= r_d[:, :-1] != r_d[:, 1:]
+    assert np.array_equal(ids.numpy()[uniq], r_ids[uniq])
+    gt, _ = orc.bf_query(base, q, K)
+    assert recall(ids.numpy(), gt) > 0.9
+    # reference restrictions for several GPUs (ggnn.cu:299-301, 338-339)
+    with pytest.raises(RuntimeError, match="single GPU"):
+        eng.bf_query(q, K)
+    eng.set_return_results_on_gpu(True)
+    with pytest.raises(RuntimeError, match="single GPU"):
+        eng.query(q, K, 0.7)
