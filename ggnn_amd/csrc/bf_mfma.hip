@@ -24,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBfQueriesPerBlock = 128;
 constexpr int kBfTileRows = 32;
-constexpr uint32_t kBfMaxKP = 64;
+constexpr uint32_t kBfMaxKP = 120;  // lists of 128 queries must fit into LDS next to the tiles
 
 struct BfMfmaArgs {
   const void* base;
@@ -237,22 +237,31 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           if (!(dl < Ld[KP - 1]))
             continue;
           const int id = static_cast<int>(row0 + (l & 31));
-          // lane k < KP owns entry k
-          const bool own = lane < (int)KP;
-          const float cur = own ? Ld[lane] : inf_f();
-          const int curi = own ? Li[lane] : kEmptyKey;
-          const float prev = (own && lane > 0) ? Ld[lane - 1] : -inf_f();
-          const int previ = (own && lane > 0) ? Li[lane - 1] : kEmptyKey;
+          // lane owns entries k = c*64 + lane (c < 4); stable insert: everything <= dl stays,
+          // the first larger entry becomes dl, the rest shift by one
+          float cur[4], prev[4];
+          int previ[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = c * kWave + lane;
+            const bool own = k < (int)KP;
+            cur[c] = own ? Ld[k] : inf_f();
+            prev[c] = (own && k > 0) ? Ld[k - 1] : -inf_f();
+            previ[c] = (own && k > 0) ? Li[k - 1] : kEmptyKey;
+          }
           // one wave: the loads above are issued for all lanes before the stores below (LDS
           // operations of a wave execute in order); only the compiler must not reorder them
           __builtin_amdgcn_wave_barrier();
-          if (own && dl < cur) {
-            const bool first = !(dl < prev);  // previous entry stays: insert here
-            Ld[lane] = first ? dl : prev;
-            Li[lane] = first ? id : previ;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = c * kWave + lane;
+            if (k < (int)KP && dl < cur[c]) {
+              const bool first = !(dl < prev[c]);  // previous entry stays: insert here
+              Ld[k] = first ? dl : prev[c];
+              Li[k] = first ? id : previ[c];
+            }
           }
           __builtin_amdgcn_wave_barrier();
-          (void)curi;
         }
       }
     }

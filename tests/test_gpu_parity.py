@@ -430,7 +430,8 @@ def test_unsupported_shapes_fail_loudly(ops):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype,N,D,Nq,K", [("f32", 20000, 128, 300, 10), ("u8", 20000, 128, 257, 10),
                                             ("f32", 9000, 96, 400, 24), ("f32", 5000, 32, 1000, 1),
-                                            ("f32", 33333, 100, 256, 50), ("f32", 4100, 4, 260, 5)])
+                                            ("f32", 33333, 100, 256, 50), ("f32", 4100, 4, 260, 5),
+                                            ("f32", 30000, 128, 300, 100), ("u8", 9000, 64, 256, 248)])
 def test_bf_mfma_int_exact(ops, orc, dtype, N, D, Nq, K):
     base, q = _data(dtype, N, D, 61), _data(dtype, Nq, D, 62)
     ids, d = ops.bf_query(dev(base), dev(q), K)
