@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
   constexpr int EPC = ChunkOf<BaseT>::EPC;
   using Chunk = typename ChunkOf<BaseT>::type;
   const uint32_t g = threadIdx.x & 15;
-  const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint32_t row = block_linear_index() * 16 + (threadIdx.x >> 4);
   float acc = 0.f;
   if (row < N) {
     const BaseT* p = data + static_cast<size_t>(row) * D;
@@ -308,7 +308,9 @@ __global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
   float* all_d = reinterpret_cast<float*>(lds.known);
   int* all_id = lds.known + a.cap;
   const int lane = threadIdx.x;
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= a.Nq)
+    return;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   DistEngine<BaseT, LPR, NCH> de;
   de.template load_query<MODE>(base, a.D, static_cast<const BaseT*>(a.query) + static_cast<size_t>(n) * a.D);
@@ -424,9 +426,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
 
 #define GGNN_BF_MFMA(T, MODE_)                                                                    \
   do {                                                                                            \
-    hipLaunchKernelGGL((row_norms_kernel<T>), dim3((a.N_base + 15) / 16), dim3(256), 0, stream,   \
+    hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,   \
                        static_cast<const T*>(a.base), a.N_base, a.D, bnorm);                      \
-    hipLaunchKernelGGL((row_norms_kernel<T>), dim3((a.Nq + 15) / 16), dim3(256), 0, stream,       \
+    hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,       \
                        static_cast<const T*>(a.query), a.Nq, a.D, qnorm);                         \
     if (lds > 64 * 1024)                                                                          \
       GGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_>), \
@@ -434,7 +436,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                                          static_cast<int>(lds)));                                 \
     hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_>), dim3(qblocks, slices), dim3(256), lds, stream, \
                        m);                                                                        \
-    hipLaunchKernelGGL((bf_rerank_kernel<T, 16, 2, MODE_>), dim3(a.Nq), dim3(kWave), rr_lds,      \
+    hipLaunchKernelGGL((bf_rerank_kernel<T, 16, 2, MODE_>), grid_for(a.Nq), dim3(kWave), rr_lds,      \
                        stream, rr);                                                               \
   } while (0)
   if (a.dtype == GGNN_F32) {

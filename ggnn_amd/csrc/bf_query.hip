@@ -31,8 +31,11 @@ __global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
   __shared__ float s_d[ROWS * STEPS];
 
   const int lane = threadIdx.x;
-  const uint32_t n = blockIdx.x / a.slices;
-  const uint32_t slice = blockIdx.x % a.slices;
+  const uint32_t bid = block_linear_index();
+  if (bid >= a.Nq * a.slices)
+    return;
+  const uint32_t n = bid / a.slices;
+  const uint32_t slice = bid % a.slices;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
 
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
 template <typename BaseT, int LPR, int NCH, int MODE>
 static void launch_bf_r(const BfArgs& args, hipStream_t stream)
 {
-  const dim3 grid(args.Nq * args.slices);
+  const dim3 grid = grid_for(static_cast<uint64_t>(args.Nq) * args.slices);
   if (args.K <= 64)
     hipLaunchKernelGGL((bf_query_kernel<BaseT, LPR, NCH, 1, MODE>), grid, dim3(kWave), 0, stream,
                        args);

@@ -58,6 +58,24 @@ inline size_t align8(size_t s)
   return (s + 7) / 8 * 8;
 }
 
+// The AQL dispatch packet stores the grid size per dimension in WORK-ITEMS as 32 bits, so a 1-D
+// launch of more than 2^32 / block_threads workgroups is silently truncated (one wave per point
+// breaks beyond 2^26 points).  Large launches therefore use a 2-D grid; kernels recover the
+// linear workgroup index with block_linear_index() and guard against the rounded-up tail.
+constexpr uint32_t kMaxGridX = 1u << 20;
+inline dim3 grid_for(uint64_t blocks)
+{
+  if (blocks <= kMaxGridX)
+    return dim3(static_cast<uint32_t>(blocks ? blocks : 1));
+  return dim3(kMaxGridX, static_cast<uint32_t>((blocks + kMaxGridX - 1) / kMaxGridX));
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t block_linear_index()
+{
+  return blockIdx.y * gridDim.x + blockIdx.x;
+}
+#endif
+
 extern int g_log_level;
 #define GGNN_LOG(level, ...)                 \
   do {                                       \

@@ -28,7 +28,9 @@ __global__ void __launch_bounds__(kWave) top_kernel(const TopArgs a)
   float* all_d = reinterpret_cast<float*>(lds.known);
   int* all_id = lds.known + a.cap;
   const int lane = threadIdx.x;
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= a.N_layer)
+    return;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const uint32_t K = a.KBuild;
 
@@ -119,10 +121,10 @@ void launch_top(const TopLaunch& a, hipStream_t stream)
 #define GGNN_LAUNCH_TOP(T, LPR, NCH)                                                          \
   do {                                                                                        \
     if (a.measure == GGNN_EUCLIDEAN)                                                          \
-      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kL2>), dim3(a.N_layer), dim3(kWave), lds,   \
+      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kL2>), grid_for(a.N_layer), dim3(kWave), lds,   \
                          stream, args);                                                       \
     else                                                                                      \
-      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kCos>), dim3(a.N_layer), dim3(kWave), lds,  \
+      hipLaunchKernelGGL((top_kernel<T, LPR, NCH, kCos>), grid_for(a.N_layer), dim3(kWave), lds,  \
                          stream, args);                                                       \
   } while (0)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_TOP);
@@ -150,7 +152,7 @@ struct SelectArgs {
   const int32_t* translation_layer;
   int32_t* selection_up;
   int32_t* translation_up;
-  uint32_t Sglob, S, S_offset, G, SG, SG_offset, layer;
+  uint32_t Sglob, S, S_offset, G, SG, SG_offset, layer, num_blocks;
 };
 
 __global__ void __launch_bounds__(kWave) select_kernel(const SelectArgs a)
@@ -158,7 +160,9 @@ __global__ void __launch_bounds__(kWave) select_kernel(const SelectArgs a)
   constexpr uint32_t kBlock = 128, kItems = 2;  // wrs_select_layer.cuh:40-41
   __shared__ uint32_t s_key[kBlock * kItems];
   const int lane = threadIdx.x;
-  const uint32_t b = blockIdx.x;
+  const uint32_t b = block_linear_index();
+  if (b >= a.num_blocks)
+    return;
   const uint32_t S_current = a.S + (b < a.S_offset);
   const uint32_t start = b * a.S + min(b, a.S_offset);
 
@@ -214,10 +218,11 @@ void launch_select(const ggnn_graph_config& c, uint32_t layer, const float* nn1_
   a.SG = c.SG;
   a.SG_offset = c.SG_off;
   a.layer = layer;
+  a.num_blocks = c.Bs[layer];
   // wrs_select_layer.cuh:47-48
   GGNN_REQUIRE(a.S + (a.S_offset > 0) <= 256 && a.SG + (a.SG_offset > 0) <= 256,
                GGNN_UNSUPPORTED, "segment size exceeds the selection kernel's capacity");
-  hipLaunchKernelGGL(select_kernel, dim3(c.Bs[layer]), dim3(kWave), 0, stream, a);
+  hipLaunchKernelGGL(select_kernel, grid_for(c.Bs[layer]), dim3(kWave), 0, stream, a);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 
@@ -225,9 +230,10 @@ void launch_select(const ggnn_graph_config& c, uint32_t layer, const float* nn1_
 // with an ordering that cannot be reproduced; parity of select() is tested with injected rng)
 __global__ void uniform_kernel(float* out, uint32_t n, uint64_t seed, uint64_t stream_id)
 {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n)
+  const uint64_t i64 = static_cast<uint64_t>(block_linear_index()) * blockDim.x + threadIdx.x;
+  if (i64 >= n)
     return;
+  const uint32_t i = static_cast<uint32_t>(i64);
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (stream_id * 0x100000000ull + i + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -239,7 +245,7 @@ void launch_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id, h
 {
   if (!n)
     return;
-  hipLaunchKernelGGL(uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, seed,
+  hipLaunchKernelGGL(uniform_kernel, grid_for((static_cast<uint64_t>(n) + 255) / 256), dim3(256), 0, stream, out, n, seed,
                      stream_id);
   GGNN_HIP_CHECK(hipGetLastError());
 }
@@ -251,9 +257,10 @@ void launch_uniform(float* out, uint32_t n, uint64_t seed, uint64_t stream_id, h
 __global__ void sym_buffer_merge_kernel(uint32_t K, uint32_t N, int32_t* sym_buffer,
                                         const uint32_t* sym_atomic, int32_t* graph)
 {
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N)
+  const uint64_t n64 = static_cast<uint64_t>(block_linear_index()) * blockDim.x + threadIdx.x;
+  if (n64 >= N)
     return;
+  const uint32_t n = static_cast<uint32_t>(n64);
   const uint32_t KF = K / 2, KL = K - KF;
   int32_t* s_sym = sym_buffer + static_cast<size_t>(n) * KF;
   int32_t* g_row = graph + static_cast<size_t>(n) * K + KL;
@@ -279,7 +286,7 @@ void launch_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buf
 {
   if (!N_layer)
     return;
-  hipLaunchKernelGGL(sym_buffer_merge_kernel, dim3((N_layer + 127) / 128), dim3(128), 0, stream,
+  hipLaunchKernelGGL(sym_buffer_merge_kernel, grid_for((static_cast<uint64_t>(N_layer) + 127) / 128), dim3(128), 0, stream,
                      KBuild, N_layer, sym_buffer, sym_atomic, graph_layer);
   GGNN_HIP_CHECK(hipGetLastError());
 }

@@ -35,7 +35,9 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kMergeCache);
   const int lane = threadIdx.x;
-  const uint32_t un = blockIdx.x;
+  const uint32_t un = block_linear_index();
+  if (un >= a.N_btm)
+    return;
   const int n = static_cast<int>(un);
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const uint32_t K = a.KBuild;
@@ -141,13 +143,13 @@ static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kMergeCache);
   if (args.sorted <= 64)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 256)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE>), dim3(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the merge cache");

@@ -26,7 +26,9 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, a.cache);
   const int lane = threadIdx.x;
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= a.Nq)
+    return;
 
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
@@ -95,7 +97,9 @@ __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
   float* dists = reinterpret_cast<float*>(lds_raw + a.cache);
   const WaveLds lds(lds_raw + a.cache + a.sorted, 0);
   const int lane = threadIdx.x;
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= a.Nq)
+    return;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
   const float nn1 = a.nn1_stats[1];
@@ -159,19 +163,19 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
 {
   const size_t lds = wave_lds_bytes(args.cache);
   if (sorted <= 64)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 128)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 256)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE>), dim3(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else {
     // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
     const size_t lds_big = (args.cache + sorted + WaveLds::extra_ints) * sizeof(int);
     GGNN_REQUIRE(lds_big <= 64 * 1024, GGNN_UNSUPPORTED, "cache too large for one workgroup");
-    hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE>), dim3(args.Nq), dim3(kWave),
+    hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE>), grid_for(args.Nq), dim3(kWave),
                        lds_big, stream, args);
   }
 }

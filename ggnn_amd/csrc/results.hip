@@ -25,7 +25,9 @@ __global__ void __launch_bounds__(kWave) sort_rows_kernel(uint32_t Nq, uint32_t 
   uint32_t* s_key = reinterpret_cast<uint32_t*>(lds_raw);
   int32_t* s_id = lds_raw + row_len;
   float* s_dist = reinterpret_cast<float*>(lds_raw + 2 * row_len);
-  const uint32_t n = blockIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= Nq)
+    return;
   int32_t* ri = ids + static_cast<size_t>(n) * row_len;
   float* rd = dists + static_cast<size_t>(n) * row_len;
   for (uint32_t i = threadIdx.x; i < row_len; i += kWave) {
@@ -53,7 +55,7 @@ void launch_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, floa
   if (!Nq || row_len <= 1)
     return;
   GGNN_REQUIRE(row_len <= 12000, GGNN_UNSUPPORTED, "result rows longer than 12000 entries");
-  hipLaunchKernelGGL(sort_rows_kernel, dim3(Nq), dim3(kWave), 3 * row_len * sizeof(int), stream,
+  hipLaunchKernelGGL(sort_rows_kernel, grid_for(Nq), dim3(kWave), 3 * row_len * sizeof(int), stream,
                      Nq, row_len, ids, dists);
   GGNN_HIP_CHECK(hipGetLastError());
 }

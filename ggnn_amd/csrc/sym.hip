@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(kWave) sym_kernel(const SymArgs a)
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kSymCache);
   const int lane = threadIdx.x;
-  const uint32_t un = a.first_n + blockIdx.x;
+  if (block_linear_index() >= a.count)
+    return;
+  const uint32_t un = a.first_n + block_linear_index();
   if (un >= a.N_layer)
     return;
   const int n = static_cast<int>(un);
@@ -281,10 +283,10 @@ static void launch_sym_r(const SymArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kSymCache);
   if (args.sorted <= 64)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE>), dim3(args.count), dim3(kWave), lds,
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.count), dim3(kWave), lds,
                        stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE>), dim3(args.count), dim3(kWave), lds,
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.count), dim3(kWave), lds,
                        stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the sym cache");

@@ -532,3 +532,20 @@ def test_query_lds_list_for_very_large_k(ops, orc, small_graph, K, iters):
     assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
     assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
     assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+
+
+def test_two_dimensional_grids_beyond_2_20_blocks(ops, orc):
+    """More than 2^20 workgroups are launched as a 2-D grid (the AQL packet holds the grid size in
+    work-items as 32 bits: a 1-D grid of one wave per point is silently truncated beyond 2^26
+    points).  N = 1.1M points makes `top` use blockIdx.y > 0; the result must still equal the
+    oracle for EVERY point."""
+    N, D, K = 1_100_000, 4, 8
+    base = make_int_data(N, D, 111)
+    cfg = orc.graph_config(N, D, K)
+    graph, nn1 = ops.top(dev(base), K, None, N, cfg.S0, cfg.S0_off, 0)
+    o_graph, o_nn1 = orc.top(base, K, None, N, cfg.S0, cfg.S0_off, 0)
+    assert np.array_equal(graph.cpu().numpy(), o_graph)
+    assert np.array_equal(nn1.cpu().numpy(), o_nn1)
+    u = ops.uniform(300_000_000, 7, 0)          # 1.17M blocks of 256 threads
+    tail = u[-1_000_000:].cpu().numpy()
+    assert tail.min() > 0.0 and tail.max() <= 1.0 and abs(tail.mean() - 0.5) < 0.01
