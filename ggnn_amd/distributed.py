@@ -78,17 +78,18 @@ class ShardedGGNN:
         P = self.world_size
         nq, stride = ids.shape
         out_device = ids.device
-        if ids.is_cuda and dist.get_backend(self.group) == "gloo":
+        # ONE collective: ids and the bit patterns of the distances travel in the same int32 buffer
+        packed = torch.cat([ids, dists.view(torch.int32)], dim=1).contiguous()
+        if packed.is_cuda and dist.get_backend(self.group) == "gloo":
             # backend without device collectives: stage the (small) candidate lists through the host
-            ids, dists = ids.cpu(), dists.cpu()
-        # dim-0 concatenation layout (valid for RCCL and gloo): [P*Nq, stride] == [P, Nq, stride]
-        g_ids = torch.empty((P * nq, stride), dtype=ids.dtype, device=ids.device)
-        g_dists = torch.empty((P * nq, stride), dtype=dists.dtype, device=dists.device)
-        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=self.group)
-        g_ids, g_dists = g_ids.to(out_device), g_dists.to(out_device)
-        return merge_gathered(g_ids.view(P, nq, stride), g_dists.view(P, nq, stride), k,
-                              self.n_local)
+            packed = packed.cpu()
+        # dim-0 concatenation layout (valid for RCCL and gloo): [P*Nq, 2*stride]
+        gathered = torch.empty((P * nq, 2 * stride), dtype=torch.int32, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        gathered = gathered.to(out_device).view(P, nq, 2 * stride)
+        g_ids = gathered[:, :, :stride].contiguous()
+        g_dists = gathered[:, :, stride:].contiguous().view(torch.float32)
+        return merge_gathered(g_ids, g_dists, k, self.n_local)
 
     def query(self, query, k_query, tau_query, max_iterations=400,
               measure=DistanceMeasure.Euclidean):

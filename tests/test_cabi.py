@@ -154,3 +154,61 @@ def test_evaluator_matches_oracle(orc, measure):
     ref = orc.evaluate(None, None, gt, 10, res)
     assert np.isnan(got.c1_dup) and "(duplicates unknown)" in repr(got)
     np.testing.assert_allclose(got.c_k_query, ref["c_k_query"], rtol=1e-6)
+
+
+def test_reference_python_examples_api_conformance():
+    """Every module attribute, GGNN/Evaluator method and keyword argument used by the reference's
+    examples/python/*.py exists with the same name here (checked by parsing the examples; only
+    where the reference tree is mounted)."""
+    import ast
+    import glob
+    import inspect
+
+    import ggnn
+    files = sorted(glob.glob("/root/reference/examples/python/*.py"))
+    if not files:
+        pytest.skip("reference tree not mounted")
+    checked = 0
+    for path in files:
+        tree = ast.parse(open(path).read())
+        instances = {}   # variable name -> class
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.value, ast.Call):
+                f = node.value.func
+                if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id == "ggnn":
+                    for t in node.targets:
+                        if isinstance(t, ast.Name):
+                            instances[t.id] = getattr(ggnn, f.attr, None)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name):
+                if node.value.id == "ggnn":
+                    assert hasattr(ggnn, node.attr), f"{path}: ggnn.{node.attr} missing"
+                    checked += 1
+            if not isinstance(node, ast.Call):
+                continue
+            f = node.func
+            target = None
+            if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name):
+                if f.value.id == "ggnn":
+                    target = getattr(ggnn, f.attr)
+                    target = target.__init__ if inspect.isclass(target) and f.attr != "DistanceMeasure" else target
+                elif f.value.id in instances and inspect.isclass(instances[f.value.id]):
+                    assert hasattr(instances[f.value.id], f.attr), f"{path}: .{f.attr} missing"
+                    target = getattr(instances[f.value.id], f.attr)
+            elif (isinstance(f, ast.Attribute) and isinstance(f.value, ast.Attribute) and
+                  isinstance(f.value.value, ast.Name) and f.value.value.id == "ggnn"):
+                cls = getattr(ggnn, f.value.attr)          # e.g. ggnn.FloatDataset.load
+                assert hasattr(cls, f.attr), f"{path}: ggnn.{f.value.attr}.{f.attr} missing"
+                target = getattr(cls, f.attr)
+            if target is None or not node.keywords:
+                continue
+            try:
+                params = inspect.signature(target).parameters
+            except (TypeError, ValueError):
+                continue
+            if any(p.kind == p.VAR_KEYWORD for p in params.values()):
+                continue
+            for kw in node.keywords:
+                assert kw.arg in params, f"{path}: keyword {kw.arg} not accepted by {f.attr}"
+                checked += 1
+    assert checked > 30
