@@ -62,7 +62,7 @@ def recall_at_k(ids, gt):
     return (ids.unsqueeze(2) == gt.unsqueeze(1)).any(2).float().mean().item()
 
 
-def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=15.0):
+def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=12.0):
     """Oracle timed on the host cores: brute force (the 'reference CPU brute force' of
     BASELINE.json, a port because the reference has none) and the traversal port."""
     from oracle import oracle as orc
@@ -71,12 +71,13 @@ def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=15.0):
     base_h = base.cpu().numpy()
     q_h = query.cpu().numpy()
     # calibrate on a few queries, then size the sample for ~budget_s
-    probe = max(1, min(cores, q_h.shape[0]))
+    # (the fast port handles queries in groups of 16 per thread: probe with whole groups)
+    probe = max(16, min(16 * cores, q_h.shape[0], 1024))
     t = time.perf_counter()
     orc.bf_query(base_h, q_h[:probe], k, threads=cores)
     dt = max(time.perf_counter() - t, 1e-3)
     rate = probe / dt
-    n = int(max(probe, min(q_h.shape[0], rate * budget_s)))
+    n = int(max(probe, min(q_h.shape[0], rate * budget_s, 3000)))
     t = time.perf_counter()
     orc.bf_query(base_h, q_h[:n], k, threads=cores)
     bf_s = time.perf_counter() - t
