@@ -104,6 +104,100 @@ __global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
   }
 }
 
+// k > 256: the K-best list lives in LDS (dists [K] | ids [K]); stable insertion by a wave-wide
+// shift, rare after the first few thousand rows.
+template <typename BaseT, int LPR, int NCH, int MODE>
+__global__ void __launch_bounds__(kWave) bf_query_lds_kernel(const BfArgs a)
+{
+  constexpr int ROWS = kWave / LPR;
+  constexpr int STEPS = StepsOf<LPR, NCH>::value;
+  using DE = DistEngine<BaseT, LPR, NCH>;
+  using Chunk = typename DE::Chunk;
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  float* best_d = reinterpret_cast<float*>(lds_raw);
+  int* best_i = lds_raw + a.K;
+  float* s_d = reinterpret_cast<float*>(lds_raw + 2 * a.K);
+
+  const int lane = threadIdx.x;
+  const uint32_t bid = block_linear_index();
+  if (bid >= a.Nq * a.slices)
+    return;
+  const uint32_t n = bid / a.slices;
+  const uint32_t slice = bid % a.slices;
+  const BaseT* base = static_cast<const BaseT*>(a.base);
+  DE de;
+  de.template load_query<MODE>(base, a.D, static_cast<const BaseT*>(a.query) + static_cast<size_t>(n) * a.D);
+  const int grp = lane / LPR;
+  for (uint32_t i = lane; i < a.K; i += kWave) {
+    best_d[i] = inf_f();
+    best_i[i] = kEmptyKey;
+  }
+  __syncthreads();
+
+  const uint32_t begin = slice * a.rows_per_slice;
+  const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
+  for (uint32_t i0 = begin; i0 < end; i0 += ROWS * STEPS) {
+    Chunk v[STEPS][NCH];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const uint32_t row = i0 + s * ROWS + grp;
+      const bool valid = row < end;
+      const BaseT* rp = de.row_ptr(valid ? row : begin);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        v[s][c] = ChunkOf<BaseT>::zero();
+        if (valid && de.chunk_valid(c))
+          v[s][c] = de.load_chunk(rp, c);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      float x, y;
+      de.template partial<MODE>(v[s], x, y);
+      x = group_sum<LPR>(x);
+      if (MODE == kCos)
+        y = group_sum<LPR>(y);
+      if (de.g == 0)
+        s_d[s * ROWS + grp] = (MODE == kCos) ? de.finish_cos(x, y) : x;
+    }
+    __syncthreads();
+    const uint32_t cnt = min((uint32_t)(ROWS * STEPS), end - i0);
+    const float cd = lane < (int)cnt ? s_d[lane] : inf_f();
+    unsigned long long m = __ballot(cd < best_d[a.K - 1]);
+    while (m) {
+      const int j = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const float d = rdlanef(cd, j);
+      if (!(d < best_d[a.K - 1]))
+        continue;
+      // stable insert (k_best_list.cuh:77-109): chunks from the right so that every entry is
+      // read before it is overwritten
+      const int id = static_cast<int>(i0 + j);
+      for (int c0 = (static_cast<int>(a.K) - 1) / kWave * kWave; c0 >= 0; c0 -= kWave) {
+        const int k = c0 + lane;
+        const bool own = k < static_cast<int>(a.K);
+        const float cur = own ? best_d[k] : inf_f();
+        const float prev = (own && k > 0) ? best_d[k - 1] : -inf_f();
+        const int previ = (own && k > 0) ? best_i[k - 1] : kEmptyKey;
+        __syncthreads();
+        if (own && d < cur) {
+          const bool first = !(d < prev);
+          best_d[k] = first ? d : prev;
+          best_i[k] = first ? id : previ;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  const size_t out = (static_cast<size_t>(slice) * a.Nq + n) * a.K;
+  for (uint32_t i = lane; i < a.K; i += kWave) {
+    a.ids[out + i] = best_i[i];
+    a.dists[out + i] = best_d[i];
+  }
+}
+
 template <typename BaseT, int LPR, int NCH, int MODE>
 static void launch_bf_r(const BfArgs& args, hipStream_t stream)
 {
@@ -118,7 +212,8 @@ static void launch_bf_r(const BfArgs& args, hipStream_t stream)
     hipLaunchKernelGGL((bf_query_kernel<BaseT, LPR, NCH, 4, MODE>), grid, dim3(kWave), 0, stream,
                        args);
   else
-    throw Error(GGNN_UNSUPPORTED, "bf_query supports k_gt <= 256 in this build");
+    hipLaunchKernelGGL((bf_query_lds_kernel<BaseT, LPR, NCH, MODE>), grid, dim3(kWave),
+                       (2 * args.K + 64) * sizeof(int), stream, args);
 }
 
 bool bf_mfma_supported(const BfLaunch& a);

@@ -41,6 +41,15 @@ def test_bf_query_int_exact(ops, orc, N, D, Nq, K):
     assert np.array_equal(d.cpu().numpy(), o_d)
 
 
+@pytest.mark.parametrize("N,D,Nq,K", [(3000, 32, 9, 300), (1500, 16, 3, 1000), (50000, 32, 4, 257)])
+def test_bf_query_very_large_k(ops, orc, N, D, Nq, K):
+    base, q = make_int_data(N, D, 13), make_int_data(Nq, D, 14)
+    ids, d = ops.bf_query(dev(base), dev(q), K)
+    o_ids, o_d = orc.bf_query(base, q, K)
+    assert np.array_equal(ids.cpu().numpy(), o_ids)
+    assert np.array_equal(d.cpu().numpy(), o_d)
+
+
 def test_bf_query_ties_lower_index_first(ops, orc):
     # duplicated base rows: equal distances must keep the lower base index first (Q2)
     base = make_int_data(500, 64, 3)
