@@ -52,6 +52,10 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
     cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr);
   }
 
+  // Speculation that hides one of the two dependent memory latencies per pop: while the distance
+  // phase of this pop runs, the graph row of the current queue head is already loaded; if that
+  // key is still the head at the next pop (no closer candidate was pushed) the row is there.
+  int spec_key = kEmptyKey, spec_row = kEmptyKey;
   for (uint32_t ite = 0; ite < a.max_iters; ++ite) {
     // query_layer.cu:58-63
     const float d0 = sl.dist_at(0);
@@ -63,7 +67,19 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
     // query_layer.cu:69-77
     const int32_t* row = a.graph0 + static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild;
     for (uint32_t i = 0; i < a.KBuild; i += kKBlock) {
-      const int cand = (lane < (int)kKBlock && i + lane < a.KBuild) ? row[i + lane] : kEmptyKey;
+      const bool in_row = lane < (int)kKBlock && i + lane < a.KBuild;
+      int cand;
+      if (i == 0 && anchor == spec_key)
+        cand = spec_row;
+      else
+        cand = in_row ? row[i + lane] : kEmptyKey;
+      if (i == 0) {
+        spec_key = sl.key_at(sl.BEST);
+        if (spec_key != kEmptyKey)
+          spec_row = in_row ? a.graph0[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
+                                           a.KBuild + lane]
+                            : kEmptyKey;
+      }
       cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr);
     }
   }
