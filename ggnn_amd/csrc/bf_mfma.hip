@@ -16,6 +16,8 @@
 //      returned distances are the direct-form values; the expanded form only pre-selects.
 //      On integer-valued data (<= 2^24) both forms are exact and the result is bit-identical to
 //      the scan kernel and to the oracle.
+#include <cstdlib>
+
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -376,7 +378,12 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const uint32_t Dh = ((a.D + 1) / 2 + 3) / 4 * 4;
   const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
   const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
-  uint32_t slices = std::max(1u, std::min(32u, (768u + qblocks - 1) / qblocks));
+  // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
+  // second round costs more than the lower parallelism (measured: 790 blocks 39.8 ms, 474 blocks
+  // 31.5 ms for 10k x 1M x 128)
+  uint32_t slices = std::max(1u, std::min(32u, 512u / std::max(1u, qblocks)));
+  if (const char* e = std::getenv("GGNN_BF_SLICES"))  // tuning hook
+    slices = std::max(1u, std::min(64u, static_cast<uint32_t>(std::atoi(e))));
   uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;

@@ -104,8 +104,9 @@ inline size_t wave_lds_bytes(uint32_t cache)
 // ---------------------------------------------------------------------------------------------
 // Sorted part of the cache: logical entry i = r*64 + lane.
 //   [0,BEST) best list, [BEST,SORTED) priority queue in logical order (head first).
-// Reference: SimpleKNNCache, simple_knn_cache.cuh:58-352.  TIES_AFTER selects the KBestList
-// tie rule (k_best_list.cuh:92-103) instead of the cache's (Q2).
+// Reference: SimpleKNNCache, simple_knn_cache.cuh:58-352.  push() follows the cache's tie rule
+// (Q2: a new equal distance goes first), push_best_stable() the KBestList's (k_best_list.cuh:
+// 92-103: equal distances keep insertion order).
 // ---------------------------------------------------------------------------------------------
 template <int R>
 struct SortedList {
