@@ -65,28 +65,33 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
 }
 
 // ---- 2. tile kernel -------------------------------------------------------------------------------
+// The K dimension is processed in chunks of CW = 2*Dh columns (Dh = 64 when D > 128, otherwise
+// ceil(D/2) rounded up to the vector width).  Lane (j, h) of a wave owns chunk columns
+// [h*Dh, (h+1)*Dh) of base row j (B operand) and of query row j (A operand), so MFMA step kk
+// contracts global dimension col0 + h*Dh + kk -- any pairing works as long as A and B agree.
 template <typename BaseT>
 struct TileStage;
 
-// f32: D/4 float4 chunks per row, 32 rows -> 8*D chunks... (D <= 128 => <= 4 per thread)
+// f32: CW/4 float4 per row, 32 rows -> at most 1024 float4 = 4 per thread
 template <>
 struct TileStage<float> {
   float4 r[4];
-  GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end)
+  GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
+                     uint32_t CW)
   {
-    const uint32_t cpr = D / 4;
+    const uint32_t cpr = CW / 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
-      const uint32_t row = idx / cpr, c4 = idx % cpr;
+      const uint32_t row = idx / cpr, col = col0 + 4 * (idx % cpr);
       r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < (uint32_t)kBfTileRows && row0 + row < end)
-        r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + 4 * c4);
+      if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D)
+        r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + col);
     }
   }
-  GGNN_DEV void store(float* tile, uint32_t D, uint32_t DP) const
+  GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
   {
-    const uint32_t cpr = D / 4;
+    const uint32_t cpr = CW / 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
@@ -97,21 +102,22 @@ struct TileStage<float> {
   }
 };
 
-// u8: D/16 chunks of 16 bytes per row, 32 rows -> 2*D <= 256 chunks, one per thread
+// u8: CW/16 chunks of 16 bytes per row, 32 rows -> at most 256 chunks, one per thread
 template <>
 struct TileStage<uint8_t> {
   uint4 r;
-  GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end)
+  GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
+                     uint32_t CW)
   {
-    const uint32_t cpr = D / 16;
-    const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
+    const uint32_t cpr = CW / 16;
+    const uint32_t row = threadIdx.x / cpr, col = col0 + 16 * (threadIdx.x % cpr);
     r = make_uint4(0u, 0u, 0u, 0u);
-    if (row < (uint32_t)kBfTileRows && row0 + row < end)
-      r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + row) * D + 16 * c);
+    if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D)
+      r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + row) * D + col);
   }
-  GGNN_DEV void store(float* tile, uint32_t D, uint32_t DP) const
+  GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
   {
-    const uint32_t cpr = D / 16;
+    const uint32_t cpr = CW / 16;
     const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
     if (row < (uint32_t)kBfTileRows) {
       float* dst = tile + row * DP + 16 * c;
@@ -128,7 +134,38 @@ struct TileStage<uint8_t> {
   }
 };
 
-template <typename BaseT, int MODE>
+// A operand of one chunk: aq[kk] = q[col0 + h*Dh + kk] (0 outside the row / the query set)
+GGNN_DEV void load_query_chunk(float (&aq)[64], const float* qrow, bool qvalid, uint32_t D,
+                               uint32_t Dh, uint32_t col_h)
+{
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qvalid && static_cast<uint32_t>(4 * t) < Dh && col_h + 4 * t < D)
+      v = *reinterpret_cast<const float4*>(qrow + col_h + 4 * t);
+    aq[4 * t + 0] = v.x;
+    aq[4 * t + 1] = v.y;
+    aq[4 * t + 2] = v.z;
+    aq[4 * t + 3] = v.w;
+  }
+}
+GGNN_DEV void load_query_chunk(float (&aq)[64], const uint8_t* qrow, bool qvalid, uint32_t D,
+                               uint32_t Dh, uint32_t col_h)
+{
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (qvalid && static_cast<uint32_t>(16 * t) < Dh && col_h + 16 * t < D)
+      v = *reinterpret_cast<const uint4*>(qrow + col_h + 16 * t);
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      aq[16 * t + e] = ChunkOf<uint8_t>::get(v, e);
+  }
+}
+
+// T = base tiles per group whose accumulators stay in registers while the K chunks stream by
+// (T = 1 for D <= 128: a single chunk, the query tile is loaded once per workgroup)
+template <typename BaseT, int MODE, int T>
 __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -144,87 +181,112 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
   const uint32_t begin = blockIdx.y * a.rows_per_slice;
   const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
   const uint32_t KP = a.KP;
+  const uint32_t CW = 2 * a.Dh;
+  const uint32_t nch = (a.D + CW - 1) / CW;
 
-  // zero both tiles once: columns >= D (padding of the K dimension) must contribute 0
-  for (uint32_t i = tid; i < 2 * kBfTileRows * a.DP; i += 256)
-    lds_f[i] = 0.f;
-  __syncthreads();
-  // candidate lists of this wave's 32 queries
+  // candidate lists of this wave's 32 queries; padding queries get -inf so that nothing ever
+  // beats their threshold (their lists are never written out)
   for (uint32_t i = lane; i < 32 * KP; i += 64) {
-    list_d[wave * 32 * KP + i] = inf_f();
+    list_d[wave * 32 * KP + i] = (qbase + i / KP < a.Nq) ? inf_f() : -inf_f();
     list_id[wave * 32 * KP + i] = kEmptyKey;
   }
 
-  // A operand: lane (i=j, h) holds q[qbase+i][h*Dh + kk], kk < Dh (zero outside D / Nq)
+  const bool qvalid = qbase + j < a.Nq;
+  const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
   float aq[64];
-  {
-    const bool qvalid = qbase + j < a.Nq;
-    const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t kk = 4 * t + e;
-        const uint32_t d = h * a.Dh + kk;
-        aq[kk] = (qvalid && kk < a.Dh && d < a.D) ? static_cast<float>(qrow[d]) : 0.f;
-      }
-    }
-  }
   // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
-  float qn[16], thr[16];
+  float qn[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
     qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
-    thr[r] = qi < a.Nq ? inf_f() : -inf_f();  // padding queries never take the insertion path
   }
 
   TileStage<BaseT> stage;
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
-    stage.load(base, a.D, begin, end);
-    stage.store(tile[0], a.D, a.DP);
+    stage.load(base, a.D, begin, end, 0, CW);
+    stage.store(tile[0], a.DP, CW);
   }
   __syncthreads();
 
-  for (uint32_t tt = 0; tt < ntiles; ++tt) {
-    const uint32_t row0 = begin + tt * kBfTileRows;
-    if (tt + 1 < ntiles)
-      stage.load(base, a.D, row0 + kBfTileRows, end);
-    const bool jvalid = row0 + j < end;
-    const float bn = jvalid ? a.bnorm[row0 + j] : 0.f;
-
-    // S = Q x B^T for this wave's 32 queries against the 32 tile rows
-    const float* bt = tile[tt & 1] + j * a.DP + h * a.Dh;
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t p = 0;  // (tile, chunk) pairs processed: buffer p&1 holds the current pair
+  for (uint32_t g0 = 0; g0 < ntiles; g0 += T) {
+    f32x16 acc[T];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      if (static_cast<uint32_t>(4 * t) < a.Dh) {
-        const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * t);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 0], bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 1], bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 2], bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * t + 3], bv.w, acc, 0, 0, 0);
+    for (int t = 0; t < T; ++t)
+      acc[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (uint32_t c = 0; c < nch; ++c) {
+      if (nch > 1 || g0 == 0)
+        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, c * CW + h * a.Dh);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const uint32_t tt = g0 + t;
+        if (tt >= ntiles)
+          break;  // uniform
+        // the pair after this one: next tile of the group, else next chunk, else next group
+        bool has_next = true;
+        uint32_t n_tile = tt + 1, n_chunk = c;
+        if (!(t + 1 < T && tt + 1 < ntiles)) {
+          if (c + 1 < nch) {
+            n_tile = g0;
+            n_chunk = c + 1;
+          }
+          else if (g0 + T < ntiles) {
+            n_tile = g0 + T;
+            n_chunk = 0;
+          }
+          else
+            has_next = false;
+        }
+        if (has_next)
+          stage.load(base, a.D, begin + n_tile * kBfTileRows, end, n_chunk * CW, CW);
+
+        // S += Q_chunk x B_chunk^T for this wave's 32 queries against the 32 tile rows
+        const float* bt = tile[p & 1] + j * a.DP + h * a.Dh;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (static_cast<uint32_t>(4 * u) < a.Dh) {
+            const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc[t], 0, 0, 0);
+          }
+        }
+        if (has_next)
+          stage.store(tile[(p + 1) & 1], a.DP, CW);
+        __syncthreads();
+        ++p;
       }
     }
 
     // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows
-    bool refresh = false;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d;
-      if (MODE == kL2) {
-        d = fmaf(-2.0f, acc[r], qn[r] + bn);
-      }
-      else {
-        const float norm_sqr = qn[r] * bn;
-        d = (norm_sqr > 0.0f) ? fabsf(1.0f - acc[r] / sqrtf(norm_sqr)) : 1.0f;
-      }
-      if (!jvalid)
-        d = inf_f();
-      unsigned long long m = __ballot(d < thr[r]);
-      if (m) {
-        refresh = true;
+    for (int t = 0; t < T; ++t) {
+      const uint32_t tt = g0 + t;
+      if (tt >= ntiles)
+        break;
+      const uint32_t row0 = begin + tt * kBfTileRows;
+      const bool jvalid = row0 + j < end;
+      const float bn = jvalid ? a.bnorm[row0 + j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d;
+        if (MODE == kL2) {
+          d = fmaf(-2.0f, acc[t][r], qn[r] + bn);
+        }
+        else {
+          const float norm_sqr = qn[r] * bn;
+          d = (norm_sqr > 0.0f) ? fabsf(1.0f - acc[t][r] / sqrtf(norm_sqr)) : 1.0f;
+        }
+        if (!jvalid)
+          d = inf_f();
+        // threshold = current worst list entry of the query this register row belongs to
+        const int qi_own = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float thr = list_d[(wave * 32 + qi_own) * KP + KP - 1];
+        unsigned long long m = __ballot(d < thr);
         // rare path: stable insertion, candidates in ascending lane order (= ascending base
         // index within each query row)
         while (m) {
@@ -232,8 +294,6 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           m &= m - 1;
           const float dl = rdlanef(d, l);
           const int qi = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-          if (qbase + qi >= a.Nq)
-            continue;
           float* Ld = list_d + (wave * 32 + qi) * KP;
           int* Li = list_id + (wave * 32 + qi) * KP;
           if (!(dl < Ld[KP - 1]))
@@ -267,18 +327,6 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
         }
       }
     }
-    if (refresh) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (qbase + qi < a.Nq)
-          thr[r] = list_d[(wave * 32 + qi) * KP + KP - 1];
-      }
-    }
-
-    if (tt + 1 < ntiles)
-      stage.store(tile[(tt + 1) & 1], a.D, a.DP);
-    __syncthreads();
   }
 
   // partial results of this base slice
@@ -366,8 +414,7 @@ __global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
 bool bf_mfma_supported(const BfLaunch& a)
 {
   const uint32_t epc = a.dtype == GGNN_F32 ? 4 : 16;
-  return a.D <= 128 && a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 &&
-         a.N_base >= 4096;
+  return a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 && a.N_base >= 4096;
 }
 
 void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
@@ -375,7 +422,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   check_vector_layout(a.base, a.D, a.dtype);
   check_vector_layout(a.query, a.D, a.dtype);
   const uint32_t KP = a.k_query + 8;  // margin against rounding of the expanded distance form
-  const uint32_t Dh = ((a.D + 1) / 2 + 3) / 4 * 4;
+  const uint32_t vec = a.dtype == GGNN_F32 ? 4 : 16;
+  // one chunk of 2*Dh columns when the row fits (D <= 128), otherwise chunks of 128 columns
+  const uint32_t Dh = a.D > 128 ? 64 : (((a.D + 1) / 2 + vec / 2 - 1) / (vec / 2) * (vec / 2) + 3) / 4 * 4;
   const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
   const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
   // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
@@ -438,13 +487,20 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,       \
                        static_cast<const T*>(a.query), a.Nq, a.D, qnorm);                         \
     if (lds > 64 * 1024)                                                                          \
-      GGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                         static_cast<int>(lds)));                                 \
-    hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_>), dim3(qblocks, slices), dim3(256), lds, stream, \
-                       m);                                                                        \
-    hipLaunchKernelGGL((bf_rerank_kernel<T, 16, 2, MODE_>), grid_for(a.Nq), dim3(kWave), rr_lds,      \
-                       stream, rr);                                                               \
+    {                                                                                             \
+      GGNN_HIP_CHECK(hipFuncSetAttribute(                                                         \
+          reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1>),                            \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+      GGNN_HIP_CHECK(hipFuncSetAttribute(                                                         \
+          reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4>),                            \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
+    }                                                                                             \
+    if (a.D > 128)                                                                                \
+      hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_, 4>), dim3(qblocks, slices), dim3(256), lds,    \
+                         stream, m);                                                              \
+    else                                                                                          \
+      hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_, 1>), dim3(qblocks, slices), dim3(256), lds,    \
+                         stream, m);                                                              \
   } while (0)
   if (a.dtype == GGNN_F32) {
     if (a.measure == GGNN_EUCLIDEAN)
@@ -459,6 +515,18 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
       GGNN_BF_MFMA(uint8_t, kCos);
   }
 #undef GGNN_BF_MFMA
+  GGNN_HIP_CHECK(hipGetLastError());
+#define GGNN_BF_RERANK(T, LPR, NCH)                                                                \
+  do {                                                                                             \
+    if (a.measure == GGNN_EUCLIDEAN)                                                               \
+      hipLaunchKernelGGL((bf_rerank_kernel<T, LPR, NCH, kL2>), grid_for(a.Nq), dim3(kWave), rr_lds, \
+                         stream, rr);                                                              \
+    else                                                                                           \
+      hipLaunchKernelGGL((bf_rerank_kernel<T, LPR, NCH, kCos>), grid_for(a.Nq), dim3(kWave),       \
+                         rr_lds, stream, rr);                                                      \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_BF_RERANK);
+#undef GGNN_BF_RERANK
   GGNN_HIP_CHECK(hipGetLastError());
   GGNN_HIP_CHECK(hipFreeAsync(norms, stream));
   GGNN_HIP_CHECK(hipFreeAsync(part_ids, stream));

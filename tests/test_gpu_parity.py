@@ -440,7 +440,10 @@ def test_unsupported_shapes_fail_loudly(ops):
 @pytest.mark.parametrize("dtype,N,D,Nq,K", [("f32", 20000, 128, 300, 10), ("u8", 20000, 128, 257, 10),
                                             ("f32", 9000, 96, 400, 24), ("f32", 5000, 32, 1000, 1),
                                             ("f32", 33333, 100, 256, 50), ("f32", 4100, 4, 260, 5),
-                                            ("f32", 30000, 128, 300, 100), ("u8", 9000, 64, 256, 248)])
+                                            ("f32", 30000, 128, 300, 100), ("u8", 9000, 64, 256, 248),
+                                            ("f32", 9000, 256, 300, 10), ("f32", 6000, 960, 260, 10),
+                                            ("u8", 8000, 960, 256, 20), ("f32", 5000, 132, 256, 10),
+                                            ("f32", 4500, 1024, 256, 5)])
 def test_bf_mfma_int_exact(ops, orc, dtype, N, D, Nq, K):
     base, q = _data(dtype, N, D, 61), _data(dtype, Nq, D, 62)
     ids, d = ops.bf_query(dev(base), dev(q), K)
@@ -459,9 +462,9 @@ def test_bf_mfma_ties_and_duplicates(ops, orc):
     assert np.array_equal(d.cpu().numpy(), o_d)
 
 
-@pytest.mark.parametrize("measure", [0, 1])
-def test_bf_mfma_float_tolerance(ops, orc, measure):
-    base, q = make_uni_data(30000, 128, 7), make_uni_data(300, 128, 8)
+@pytest.mark.parametrize("measure,D", [(0, 128), (1, 128), (0, 960), (1, 960)])
+def test_bf_mfma_float_tolerance(ops, orc, measure, D):
+    base, q = make_uni_data(12000, D, 7), make_uni_data(300, D, 8)
     ids, d = ops.bf_query(dev(base), dev(q), 10, measure)
     o_ids, o_d = orc.bf_query(base, q, 10, measure)
     np.testing.assert_allclose(d.cpu().numpy(), o_d, rtol=RTOL, atol=1e-7)
