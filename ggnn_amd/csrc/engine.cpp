@@ -750,9 +750,23 @@ struct ggnn_handle {
 namespace {
 thread_local std::string g_create_error;
 
+// the engine switches devices (hipSetDevice) while it works; callers such as PyTorch keep their
+// own notion of the current device, so every entry point leaves it as it found it
+struct DeviceRestore {
+  int prev{-1};
+  DeviceRestore() { (void)hipGetDevice(&prev); }
+  ~DeviceRestore()
+  {
+    int now = -1;
+    if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev)
+      (void)hipSetDevice(prev);
+  }
+};
+
 template <typename F>
 ggnn_status guarded(ggnn_t* h, F&& f)
 {
+  DeviceRestore restore;
   try {
     f();
     return GGNN_OK;
@@ -792,6 +806,7 @@ ggnn_status ggnn_create(ggnn_t** out)
 
 void ggnn_destroy(ggnn_t* h)
 {
+  DeviceRestore restore;
   delete h;
 }
 
