@@ -1358,6 +1358,18 @@ static float bits_to_float(int32_t b)
   return f;
 }
 
+// KBestList driven by a (dist, id) stream, as bf_query (check_worst) or top (no check) use it
+void orc_kbest_script(uint32_t BEST, uint32_t BLOCK, const float* dists, const int32_t* ids,
+                      uint32_t n, int check_worst, float* out_d, int32_t* out_i)
+{
+  KBest best(BEST, BLOCK);
+  for (uint32_t i = 0; i < n; ++i)
+    if (!check_worst || dists[i] < best.worst())
+      best.add_unique(dists[i], ids[i]);
+  std::memcpy(out_d, best.d.data(), BEST * sizeof(float));
+  std::memcpy(out_i, best.id.data(), BEST * sizeof(int32_t));
+}
+
 void orc_cache_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, uint32_t BLOCK, float xi,
                       const int32_t* ops, uint32_t n_ops, int32_t* out_keys, float* out_dists,
                       int32_t* out_pops, uint32_t* out_heads)

@@ -5,12 +5,15 @@
 // kernels in ggnn_amd/csrc.  Nothing under ggnn_amd/ may include, link or call
 // it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
 //
-// PARITY UNPINNED: the reference has no tests, no golden vectors and no CPU
-// implementation of this path, and none of its translation units can be built
-// in this image without stand-ins (needs nvcc, glog, nanobind).  The oracle is
-// therefore pinned only by (a) hand-derived known-answer tests written from
-// the cited reference lines and (b) the GraphConfig numbers recorded in
-// SURVEY.md section 8(a) row L (tests/golden/graph_config.json).
+// PARITY MOSTLY UNPINNED: the reference has no tests, no golden vectors and no
+// CPU implementation of this path, and none of its translation units can be
+// built in this image without stand-ins (needs nvcc, glog, CUB, nanobind).
+// Pinned: (a) KBestList -- the reference's own k_best_list.cuh compiles
+// unchanged with hipcc (oracle/_ref, tests/test_gpu_ref_kbest.py runs it on
+// the GPU against the emulation here); (b) the GraphConfig numbers recorded in
+// SURVEY.md section 8(a) row L (tests/golden/graph_config.json); (c) hand-
+// derived known-answer tests written from the cited reference lines.
+// Everything that depends on CUB / cuRAND ordering stays unpinned.
 //
 // Every function cites the reference file:line it follows (paths relative to
 // /root/reference).  Block-lockstep semantics are emulated phase by phase
@@ -113,6 +116,11 @@ void orc_merge_results(uint32_t Nq, uint32_t K, uint32_t num_gpus, uint32_t shar
 void orc_evaluate(const void* base, uint32_t N, const void* query, uint32_t Nq, uint32_t D,
                   int dtype, int measure, const int32_t* gt, uint32_t gt_D, uint32_t KQuery,
                   const int32_t* results, uint32_t Nres, float* out);
+
+// KBestList (k_best_list.cuh:29-142) driven by a stream of (dist, id) pairs; checked against the
+// reference's own device code where oracle/_ref is available (tests/test_gpu_ref_kbest.py)
+void orc_kbest_script(uint32_t BEST, uint32_t BLOCK, const float* dists, const int32_t* ids,
+                      uint32_t n, int check_worst, float* out_d, int32_t* out_i);
 
 // ---- known-answer / design-validation helpers --------------------------------------------
 // Literal emulation of SimpleKNNCache (simple_knn_cache.cuh:58-352) driven by an op script.

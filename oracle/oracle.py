@@ -289,6 +289,19 @@ def _script(fn, BEST, SORTED, CACHE, xi, ops, BLOCK=None):
     return keys, dists, pops, heads
 
 
+def kbest_script(BEST, BLOCK, dists, ids, check_worst=True):
+    dists = _c(dists, np.float32)
+    ids = _c(ids, np.int32)
+    out_d = np.empty(BEST, np.float32)
+    out_i = np.empty(BEST, np.int32)
+    lib().orc_kbest_script(C.c_uint32(BEST), C.c_uint32(BLOCK), _p(dists), _p(ids),
+                           C.c_uint32(dists.size), int(bool(check_worst)), _p(out_d), _p(out_i))
+    return out_d, out_i
+
+
+REF_KBEST_SO = os.path.join(_HERE, "_ref", "libggnn_ref_kbest.so")
+
+
 def cache_script(BEST, SORTED, CACHE, BLOCK, xi, ops):
     return _script(lib().orc_cache_script, BEST, SORTED, CACHE, xi, ops, BLOCK)
 
