@@ -271,3 +271,24 @@ def test_in_process_multi_gpu(orc, shard_size):
     eng.set_return_results_on_gpu(True)
     with pytest.raises(RuntimeError, match="single GPU"):
         eng.query(q, K, 0.7)
+
+
+def test_uint8_and_cosine_through_the_api(orc):
+    """uint8 base (SIFT-like) and cosine measure through the public surface incl. the Evaluator"""
+    import ggnn_amd as ggnn
+    r = np.random.default_rng(91)
+    base = r.integers(0, 256, (6000, 128)).astype(np.uint8)
+    q = r.integers(0, 256, (100, 128)).astype(np.uint8)
+    for measure in (ggnn.DistanceMeasure.Euclidean, ggnn.DistanceMeasure.Cosine):
+        eng = ggnn.GGNN()
+        eng.set_base(ggnn.UCharDataset(base))
+        eng.build(24, 0.5, 1, measure)
+        ids, d = eng.query(ggnn.UCharDataset(q), 10, 0.8, 400, measure)
+        gt, gd = eng.bf_query(q, 10, measure)
+        o_gt, o_gd = orc.bf_query(base, q, 10, int(measure))
+        if measure == ggnn.DistanceMeasure.Euclidean:
+            assert np.array_equal(gt.numpy(), o_gt) and np.array_equal(gd.numpy(), o_gd)
+        else:
+            np.testing.assert_allclose(gd.numpy(), o_gd, rtol=1e-4, atol=1e-7)
+        ev = ggnn.Evaluator(base, q, gt, 10, measure).evaluate_results(ids)
+        assert ev.c_k_query > 0.9, repr(ev)
