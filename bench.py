@@ -163,7 +163,7 @@ def main():
             dist.init_process_group(args.backend)
 
     import ggnn_amd as ggnn
-    from ggnn_amd.distributed import ShardedGGNN, merge_gathered
+    from ggnn_amd.distributed import ShardedGGNN
 
     def barrier():
         if world > 1:
