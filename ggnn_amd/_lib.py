@@ -78,11 +78,19 @@ SIGNATURES = {
     "ggnn_last_timing_ms": (_int, [_vp, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)]),
     "ggnn_last_query_counters": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_set_collect_counters": (_int, [_vp, _int]),
+    "ggnn_set_prescreen": (_int, [_vp, _int]),
+    "ggnn_last_query_rows_read": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_set_log_level": (None, [_int]),
     "ggnn_graph_config_init": (_int, [_u32, _u32, _u32, _cfgp]),
     "ggnn_query_sizing": (_int, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_op_query": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32,
                              _f32, _u32, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "ggnn_prescreen_sizes": (_int, [_u32, C.POINTER(_u32), C.POINTER(_sz), C.POINTER(_sz)]),
+    "ggnn_op_prescreen_encode": (_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "ggnn_op_prescreen_probe": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "ggnn_op_query_prescreened": (_int, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32,
+                                         _vp, _u32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp,
+                                         _vp, _vp]),
     "ggnn_op_bf_query": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp, _vp]),
     "ggnn_op_top": (_int, [_vp, _int, _u32, _int, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp,
                            _vp]),

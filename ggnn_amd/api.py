@@ -325,10 +325,21 @@ class GGNN:
     def set_collect_counters(self, enable=True):
         self._check(lib().ggnn_set_collect_counters(self._h, int(bool(enable))))
 
+    def set_prescreen(self, enable=True):
+        """Exact pre-screen of float32/Euclidean queries on an 8-bit copy of the base (an
+        extension: same results, less memory traffic; costs N x D bytes per shard)."""
+        self._check(lib().ggnn_set_prescreen(self._h, int(bool(enable))))
+
     def last_query_counters(self):
         d, p = C.c_uint64(), C.c_uint64()
         self._check(lib().ggnn_last_query_counters(self._h, C.byref(d), C.byref(p)))
         return {"n_dist": d.value, "n_pop": p.value}
+
+    def last_query_rows_read(self):
+        """float rows and 8-bit pre-screen rows read by the last query (with collect_counters)"""
+        f, c = C.c_uint64(), C.c_uint64()
+        self._check(lib().ggnn_last_query_rows_read(self._h, C.byref(f), C.byref(c)))
+        return {"float_rows": f.value, "code_rows": c.value}
 
 
 _hip = None

@@ -106,8 +106,26 @@ struct QueryLaunch {
   float* dists;
   uint32_t* n_dist;
   uint32_t* n_pop;
+  // optional pre-screen copy of the base (launch_prescreen_encode); ignored unless float32 + L2
+  const uint8_t* ps_codes{nullptr};
+  const float* ps_params{nullptr};
+  uint32_t ps_Dc{0};
+  uint32_t* n_rows{nullptr};  // optional [Nq x 2]: float rows and code rows read per query
 };
 void launch_query(const QueryLaunch& a, hipStream_t stream);
+
+// 8-bit pre-screen copy of a float32 base (prescreen.hip): codes [N x Dc], Dc = D rounded up to
+// 16; params [prescreen_param_floats(D)] floats; scratch [prescreen_scratch_floats(D)] floats.
+constexpr int kPsHeaderFloats = 8;
+inline uint32_t prescreen_code_dim(uint32_t D) { return (D + 15u) / 16u * 16u; }
+size_t prescreen_param_floats(uint32_t D);
+size_t prescreen_scratch_floats(uint32_t D);
+void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, uint8_t* codes,
+                             float* params, float* scratch, hipStream_t stream);
+void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
+                            const float* query, uint32_t Nq, const int32_t* cand, uint32_t M,
+                            const float* crit, int32_t* reject, float* s_out,
+                            hipStream_t stream);
 
 struct BfLaunch {
   const void* base;

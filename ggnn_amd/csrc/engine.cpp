@@ -8,6 +8,7 @@
 // (multi-GPU = one process per GPU, shards exchanged with an RCCL all-gather, see
 // ggnn_amd/distributed.py and DESIGN.md).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -107,6 +108,10 @@ struct Shard {
   int32_t* selection{nullptr};
   float* nn1_stats{nullptr};
   bool ready{false};
+  // 8-bit pre-screen copy of this shard's rows (prescreen.hip), made at the first Euclidean
+  // float32 query: 0 = not attempted, 1 = usable, -1 = data not codable (non-finite values)
+  DeviceBuffer ps_codes, ps_params;
+  int ps_state{0};
 
   static size_t pool_bytes(const ggnn_graph_config& c)
   {
@@ -138,7 +143,7 @@ struct DeviceCtx {
   uint32_t first_shard{0};      // global id of shards[0]
   std::vector<Shard> shards;
   float build_ms{0.f}, query_ms{0.f};
-  uint64_t n_dist{0}, n_pop{0};
+  uint64_t n_dist{0}, n_pop{0}, n_float_rows{0}, n_code_rows{0};
 
   DeviceCtx() = default;
   DeviceCtx(const DeviceCtx&) = delete;
@@ -179,6 +184,8 @@ struct ggnn_handle {
   uint32_t N_shard{0};
   bool return_results_on_gpu{false};
   bool collect_counters{false};
+  bool prescreen{std::getenv("GGNN_PRESCREEN") == nullptr ||
+                 std::string(std::getenv("GGNN_PRESCREEN")) != "0"};
 
   // base as handed over by the caller
   const void* base_src{nullptr};
@@ -201,7 +208,7 @@ struct ggnn_handle {
 
   // tracing
   float build_ms{0.f}, query_ms{0.f}, bf_ms{0.f};
-  uint64_t last_n_dist{0}, last_n_pop{0};
+  uint64_t last_n_dist{0}, last_n_pop{0}, last_float_rows{0}, last_code_rows{0};
 
   std::string last_error;
 
@@ -516,6 +523,37 @@ struct ggnn_handle {
     return s;
   }
 
+  // Pre-screen copy of shard si (traversal.hpp "Exact pre-screen"): pays when a float row spans
+  // more cache lines than its code row, i.e. from 256 bytes per row on.
+  bool ensure_prescreen(DeviceCtx& ctx, uint32_t si, ggnn_measure measure)
+  {
+    Shard& sh = ctx.shards[si];
+    if (!prescreen || base_dtype != GGNN_F32 || measure != GGNN_EUCLIDEAN || pad_D < 64)
+      return false;
+    if (sh.ps_state == 0) {
+      const uint32_t Dc = prescreen_code_dim(pad_D);
+      sh.ps_codes.alloc(static_cast<size_t>(cfg.N) * Dc);
+      sh.ps_params.alloc(prescreen_param_floats(pad_D) * 4);
+      DeviceBuffer scratch(prescreen_scratch_floats(pad_D) * 4);
+      launch_prescreen_encode(static_cast<const float*>(shard_base(ctx, si)), cfg.N, pad_D,
+                              sh.ps_codes.as<uint8_t>(), sh.ps_params.as<float>(),
+                              scratch.as<float>(), ctx.stream);
+      float header[kPsHeaderFloats];
+      GGNN_HIP_CHECK(hipMemcpyAsync(header, sh.ps_params.p, sizeof(header), hipMemcpyDeviceToHost,
+                                    ctx.stream));
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      sh.ps_state = header[4] != 0.f ? 1 : -1;
+      GGNN_LOG(1, "[GPU: %d] pre-screen copy of part %u: scale %g, max coding error %g%s",
+               ctx.device, sh.global_id, header[0], header[2],
+               sh.ps_state > 0 ? "" : " (unusable, disabled)");
+      if (sh.ps_state < 0) {
+        sh.ps_codes.release();
+        sh.ps_params.release();
+      }
+    }
+    return sh.ps_state > 0;
+  }
+
   // GPUInstance::query, gpu_instance.cu:626-743: all shards of one GPU into d_ids/d_dists
   // [Nq, K * shards_per_gpu]
   void query_device(DeviceCtx& ctx, const void* d_query, uint32_t nq, uint32_t k_query,
@@ -524,15 +562,17 @@ struct ggnn_handle {
   {
     hipStream_t stream = ctx.stream;
     const uint32_t spg = shards_per_gpu;
-    DeviceBuffer c_dist, c_pop;
+    DeviceBuffer c_dist, c_pop, c_rows;
     if (collect_counters) {
       c_dist.alloc(static_cast<size_t>(nq) * 4);
       c_pop.alloc(static_cast<size_t>(nq) * 4);
+      c_rows.alloc(static_cast<size_t>(nq) * 8);
     }
     ctx.query_ms = 0.f;
-    ctx.n_dist = ctx.n_pop = 0;
+    ctx.n_dist = ctx.n_pop = ctx.n_float_rows = ctx.n_code_rows = 0;
     std::vector<uint32_t> h_cnt;
     for (uint32_t si = 0; si < spg; ++si) {
+      const bool use_ps = ensure_prescreen(ctx, si, measure);
       const Shard& sh = ctx.shards[si];
       QueryLaunch ql{shard_base(ctx, si),
                      d_query,
@@ -555,6 +595,12 @@ struct ggnn_handle {
                      d_dists,
                      c_dist.as<uint32_t>(),
                      c_pop.as<uint32_t>()};
+      if (use_ps) {
+        ql.ps_codes = sh.ps_codes.as<uint8_t>();
+        ql.ps_params = sh.ps_params.as<float>();
+        ql.ps_Dc = prescreen_code_dim(pad_D);
+      }
+      ql.n_rows = c_rows.as<uint32_t>();
       EventTimer timer(stream);
       launch_query(ql, stream);
       const float ms = timer.stop();
@@ -569,6 +615,12 @@ struct ggnn_handle {
         GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_pop.p, nq * 4ull, hipMemcpyDeviceToHost));
         for (uint32_t v : h_cnt)
           ctx.n_pop += v;
+        h_cnt.resize(2ull * nq);
+        GGNN_HIP_CHECK(hipMemcpy(h_cnt.data(), c_rows.p, nq * 8ull, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nq; ++i) {
+          ctx.n_float_rows += h_cnt[2 * i];
+          ctx.n_code_rows += h_cnt[2 * i + 1];
+        }
       }
     }
     if (spg > 1)
@@ -587,7 +639,7 @@ struct ggnn_handle {
     GGNN_REQUIRE(!(direct && devs.size() > 1), GGNN_INVALID_STATE,
                  "Returning query results on GPU is only possible when using a single GPU.");
     query_ms = 0.f;
-    last_n_dist = last_n_pop = 0;
+    last_n_dist = last_n_pop = last_float_rows = last_code_rows = 0;
     if (!Nq)
       return;
     const uint32_t nq = static_cast<uint32_t>(Nq);
@@ -611,6 +663,8 @@ struct ggnn_handle {
       query_ms = std::max(query_ms, ctx.query_ms);  // GPUs run concurrently
       last_n_dist += ctx.n_dist;
       last_n_pop += ctx.n_pop;
+      last_float_rows += ctx.n_float_rows;
+      last_code_rows += ctx.n_code_rows;
     }
     if (direct)
       return;
@@ -876,6 +930,22 @@ ggnn_status ggnn_set_return_results_on_gpu(ggnn_t* h, int v)
   return GGNN_OK;
 }
 
+ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows)
+{
+  if (!h)
+    return GGNN_INVALID_ARGUMENT;
+  if (float_rows)
+    *float_rows = h->last_float_rows;
+  if (code_rows)
+    *code_rows = h->last_code_rows;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable)
+{
+  return guarded(h, [&] { h->prescreen = enable != 0; });
+}
+
 ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable)
 {
   GGNN_NEED_HANDLE(h);
@@ -1039,6 +1109,65 @@ ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, u
                   graph0,    KBuild,         start,         num_start,    nn1_stats, k_query,
                   tau_query, max_iterations, measure,       shards_per_gpu, on_gpu_shard, ids,
                   dists,     n_dist,         n_pop};
+    launch_query(q, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_prescreen_sizes(uint32_t D, uint32_t* code_dim, size_t* param_floats,
+                                 size_t* scratch_floats)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(D >= 1 && D <= 4096 && D % 4 == 0, GGNN_INVALID_ARGUMENT,
+                 "D must be a multiple of 4 in [4, 4096]");
+    if (code_dim)
+      *code_dim = prescreen_code_dim(D);
+    if (param_floats)
+      *param_floats = prescreen_param_floats(D);
+    if (scratch_floats)
+      *scratch_floats = prescreen_scratch_floats(D);
+  });
+}
+
+ggnn_status ggnn_op_prescreen_encode(const float* base, uint32_t N_base, uint32_t D,
+                                     uint8_t* codes, float* params, float* scratch, void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_prescreen_encode(base, N_base, D, codes, params, scratch,
+                            static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
+                                    const float* query, uint32_t Nq, const int32_t* cand,
+                                    uint32_t M, const float* crit, int32_t* reject, float* s_out,
+                                    void* stream)
+{
+  return guarded(nullptr, [&] {
+    launch_prescreen_probe(codes, params, D, query, Nq, cand, M, crit, reject, s_out,
+                           static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_query_prescreened(const float* base, uint32_t N_base, uint32_t D,
+                                      const uint8_t* codes, const float* params,
+                                      const float* query, uint32_t Nq, const int32_t* graph0,
+                                      uint32_t KBuild, const int32_t* start, uint32_t num_start,
+                                      const float* nn1_stats, uint32_t k_query, float tau_query,
+                                      uint32_t max_iterations, uint32_t shards_per_gpu,
+                                      uint32_t on_gpu_shard, int32_t* ids, float* dists,
+                                      uint32_t* n_dist, uint32_t* n_pop, uint32_t* n_rows,
+                                      void* stream)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(codes && params, GGNN_INVALID_ARGUMENT, "pre-screen buffers are null");
+    QueryLaunch q{base,      query,          GGNN_F32,       N_base,         D,         Nq,
+                  graph0,    KBuild,         start,          num_start,      nn1_stats, k_query,
+                  tau_query, max_iterations, GGNN_EUCLIDEAN, shards_per_gpu, on_gpu_shard, ids,
+                  dists,     n_dist,         n_pop};
+    q.ps_codes = codes;
+    q.ps_params = params;
+    q.ps_Dc = prescreen_code_dim(D);
+    q.n_rows = n_rows;
     launch_query(q, static_cast<hipStream_t>(stream));
   });
 }

@@ -15,12 +15,43 @@ struct QueryArgs {
   float* dists;
   uint32_t* n_dist;
   uint32_t* n_pop;
+  uint2* n_rows;
   uint32_t D, Nq, N_base, KBuild, num_start, KQuery, sorted, cache, max_iters;
   uint32_t shards_per_gpu, on_gpu_shard;
   float tau;
+  // optional pre-screen copy of the base (prescreen.hip); float32 + squared L2 only
+  const uint8_t* ps_codes;
+  const float* ps_params;
+  uint32_t ps_Dc;
 };
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE>
+// code-row layout used next to a float-row layout <LPR, NCH> (a code row has a quarter of the
+// 16-byte chunks of the float row)
+template <int LPR, int NCH>
+struct PsFor {
+  using type = Prescreen<8, 1>;
+};
+template <>
+struct PsFor<16, 4> {
+  using type = Prescreen<8, 2>;
+};
+template <>
+struct PsFor<64, 4> {
+  using type = Prescreen<16, 4>;
+};
+template <>
+struct PsFor<64, 16> {
+  using type = Prescreen<64, 4>;
+};
+
+template <class PSC, typename BaseT>
+GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
+{
+  if constexpr (PSC::enabled)
+    ps.load(a.ps_codes, a.ps_params, a.ps_Dc, reinterpret_cast<const float*>(qrow), a.D);
+}
+
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -39,17 +70,20 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
 
   DistEngine<BaseT, LPR, NCH> de;
   de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+  PSC ps;
+  load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
   SortedList<R> sl;
   sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known);
 
   uint32_t cnt_dist = 0, cnt_pop = 0;
+  uint2 cnt_rows = make_uint2(0u, 0u);
 
   // fetch_unfiltered(d_starting_points, nullptr, S), query_layer.cu:54-55
   for (uint32_t i = 0; i < a.num_start; i += kKBlock) {
     const int cand = (lane < (int)kKBlock && i + lane < a.num_start) ? a.start[i + lane]
                                                                       : kEmptyKey;
-    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr);
+    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr, ps, cnt_rows);
   }
 
   // Speculation that hides one of the two dependent memory latencies per pop: while the distance
@@ -80,7 +114,7 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
                                            a.KBuild + lane]
                             : kEmptyKey;
       }
-      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr);
+      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr, ps, cnt_rows);
     }
   }
 
@@ -100,11 +134,13 @@ __global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
       a.n_dist[n] = cnt_dist;
     if (a.n_pop)
       a.n_pop[n] = cnt_pop;
+    if (a.n_rows)
+      a.n_rows[n] = cnt_rows;
   }
 }
 
 // Same kernel with the LDS-resident list (SORTED > 256, i.e. KQuery > 239).
-template <typename BaseT, int LPR, int NCH, int MODE>
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -122,13 +158,16 @@ __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
   const float xi = (MODE == kL2) ? (nn1 * nn1) * a.tau * a.tau : nn1 * a.tau;
   DistEngine<BaseT, LPR, NCH> de;
   de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+  PSC ps;
+  load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
   LdsList sl;
   sl.init(a.KQuery, a.sorted, a.cache, xi, keys, dists);
   uint32_t cnt_dist = 0, cnt_pop = 0;
+  uint2 cnt_rows = make_uint2(0u, 0u);
   for (uint32_t i = 0; i < a.num_start; i += kKBlock) {
     const int cand = (lane < (int)kKBlock && i + lane < a.num_start) ? a.start[i + lane]
                                                                       : kEmptyKey;
-    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr);
+    cnt_dist += fetch<MODE, false>(sl, de, lds, cand, nullptr, ps, cnt_rows);
   }
   for (uint32_t ite = 0; ite < a.max_iters; ++ite) {
     __syncthreads();
@@ -141,7 +180,7 @@ __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
     const int32_t* row = a.graph0 + static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild;
     for (uint32_t i = 0; i < a.KBuild; i += kKBlock) {
       const int cand = (lane < (int)kKBlock && i + lane < a.KBuild) ? row[i + lane] : kEmptyKey;
-      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr);
+      cnt_dist += fetch<MODE, true>(sl, de, lds, cand, nullptr, ps, cnt_rows);
     }
   }
   __syncthreads();
@@ -156,6 +195,8 @@ __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
       a.n_dist[n] = cnt_dist;
     if (a.n_pop)
       a.n_pop[n] = cnt_pop;
+    if (a.n_rows)
+      a.n_rows[n] = cnt_rows;
   }
 }
 
@@ -174,26 +215,43 @@ void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_
   *sorted_size = std::max(cache < 512u ? 64u : 32u, required_sorted);
 }
 
-template <typename BaseT, int LPR, int NCH, int MODE>
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(args.cache);
   if (sorted <= 64)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 128)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 256)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE>), grid_for(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else {
     // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
     const size_t lds_big = (args.cache + sorted + WaveLds::extra_ints) * sizeof(int);
     GGNN_REQUIRE(lds_big <= 64 * 1024, GGNN_UNSUPPORTED, "cache too large for one workgroup");
-    hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE>), grid_for(args.Nq), dim3(kWave),
+    hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE, PSC>), grid_for(args.Nq), dim3(kWave),
                        lds_big, stream, args);
   }
+}
+
+template <typename BaseT, int LPR, int NCH>
+static void launch_query_cfg(const QueryArgs& args, bool use_ps, ggnn_measure measure,
+                             hipStream_t stream)
+{
+  if constexpr (std::is_same<BaseT, float>::value) {
+    if (use_ps) {
+      launch_query_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH>::type>(args, args.sorted,
+                                                                           stream);
+      return;
+    }
+  }
+  if (measure == GGNN_EUCLIDEAN)
+    launch_query_r<BaseT, LPR, NCH, kL2, NoPrescreen>(args, args.sorted, stream);
+  else
+    launch_query_r<BaseT, LPR, NCH, kCos, NoPrescreen>(args, args.sorted, stream);
 }
 
 void launch_query(const QueryLaunch& a, hipStream_t stream)
@@ -212,6 +270,7 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.dists = a.dists;
   args.n_dist = a.n_dist;
   args.n_pop = a.n_pop;
+  args.n_rows = reinterpret_cast<uint2*>(a.n_rows);
   args.D = a.D;
   args.Nq = a.Nq;
   args.N_base = a.N_base;
@@ -223,14 +282,20 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.shards_per_gpu = a.shards_per_gpu;
   args.on_gpu_shard = a.on_gpu_shard;
   args.tau = a.tau_query;
+  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32 &&
+                      a.measure == GGNN_EUCLIDEAN;
+  if (use_ps) {
+    GGNN_REQUIRE(a.ps_Dc % 16 == 0 && a.ps_Dc >= a.D && a.ps_Dc < a.D + 16,
+                 GGNN_INVALID_ARGUMENT, "pre-screen code rows must be D rounded up to 16");
+    GGNN_REQUIRE((reinterpret_cast<uintptr_t>(a.ps_codes) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.ps_params) & 15u) == 0,
+                 GGNN_INVALID_ARGUMENT, "pre-screen buffers must be 16-byte aligned");
+    args.ps_codes = a.ps_codes;
+    args.ps_params = a.ps_params;
+    args.ps_Dc = a.ps_Dc;
+  }
 
-#define GGNN_LAUNCH_QUERY(T, LPR, NCH)                                   \
-  do {                                                                   \
-    if (a.measure == GGNN_EUCLIDEAN)                                     \
-      launch_query_r<T, LPR, NCH, kL2>(args, args.sorted, stream);       \
-    else                                                                 \
-      launch_query_r<T, LPR, NCH, kCos>(args, args.sorted, stream);      \
-  } while (0)
+#define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_QUERY);
 #undef GGNN_LAUNCH_QUERY
   GGNN_HIP_CHECK(hipGetLastError());

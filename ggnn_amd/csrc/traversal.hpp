@@ -330,15 +330,26 @@ struct SortedList {
     const int E = SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
-    // min over (entry XOR cand) is 0 iff some entry equals cand (pure VALU, no SALU booleans)
-    unsigned acc = 0xffffffffu;
+    // min over (entry XOR cand) is 0 iff some entry equals cand.  Pure VALU on purpose: the
+    // v_cmp + s_or form needs fewer VALU instructions but measured slower (scalar dependency
+    // chain per entry).
     const unsigned c = static_cast<unsigned>(cand);
-    for (int t = 0; t * 8 < E; ++t) {
-      const int4 e = kp[t * 2 + h];
-      const unsigned a = min(static_cast<unsigned>(e.x) ^ c, static_cast<unsigned>(e.y) ^ c);
-      const unsigned b = min(static_cast<unsigned>(e.z) ^ c, static_cast<unsigned>(e.w) ^ c);
-      acc = min(acc, min(a, b));
+    auto fold = [c](unsigned acc, const int4& e) {
+      acc = min(min(acc, static_cast<unsigned>(e.x) ^ c), static_cast<unsigned>(e.y) ^ c);
+      return min(min(acc, static_cast<unsigned>(e.z) ^ c), static_cast<unsigned>(e.w) ^ c);
+    };
+    unsigned acc0 = 0xffffffffu, acc1 = 0xffffffffu;
+    const int4* p = kp + h;
+    const int T = (E + 7) >> 3;
+    int t = 0;
+    for (; t + 2 <= T; t += 2) {
+      const int4 e0 = p[2 * t], e1 = p[2 * t + 2];
+      acc0 = fold(acc0, e0);
+      acc1 = fold(acc1, e1);
     }
+    if (t < T)
+      acc0 = fold(acc0, p[2 * t]);
+    const unsigned acc = min(acc0, acc1);
     const unsigned other = static_cast<unsigned>(__shfl_xor(static_cast<int>(acc), 32));
     return (min(acc, other) == 0u) ? kEmptyKey : cand;
   }
@@ -637,11 +648,10 @@ struct StepsOf {
 
 // Computes the distances of the nsurv compacted candidates in lds.ckeys[0,nsurv) and leaves
 // them in lds.cd0[0,nsurv).  Out-of-range chunks are neither loaded nor accumulated.
-template <int MODE, class DE>
+template <int MODE, class DE, int STEPS = StepsOf<DE::LPR, DE::NCH>::value>
 GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
                                 const int32_t* translation)
 {
-  constexpr int STEPS = StepsOf<DE::LPR, DE::NCH>::value;
   constexpr int ROWS = DE::ROWS;
   using Chunk = typename DE::Chunk;
   const int lane = threadIdx.x;
@@ -683,11 +693,183 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact pre-screen of candidates on a compact copy of the rows (float32 rows, squared L2 only).
+//
+// ~85 % of the distance evaluations of a traversal end in "d >= criteria(): not pushed"
+// (simple_knn_cache.cuh:283-285) -- for those the value of d is irrelevant.  Every row x is
+// therefore also kept as 8-bit codes c with x^ = o + s*c (per-dimension offset o, one
+// scale s, prescreen.hip) and   e_max >= max_rows ||x - x^||.   By the triangle
+// inequality  ||q - x|| >= ||q - x^|| - e_max,  so a candidate whose bound already reaches the
+// criteria at the start of the fetch can be dropped WITHOUT reading its float row: the reference
+// would evaluate it and drop it as well (criteria() only tightens during a fetch).  Survivors of
+// the test are evaluated exactly as before, so ids, distances and counters are unchanged; only
+// HBM traffic shrinks (D bytes instead of 4D for a rejected candidate).
+//
+// The query is coded the same way (q^ = o + s*cq, cq clamped to [0,255]) and pays for it with its
+// own coding error e_q = ||q - q^||:   ||q - x|| >= ||q^ - x^|| - e_q - e_max,   where
+// ||q^ - x^||^2 = s^2 * sum (cq_d - c_d)^2 is exact integer arithmetic on v_dot4_u32_u8.
+//
+// Rounding: with u = 2^-24, q' = fl(fl(q-o) * fl(1/s)) has ||s q' - (q-o)|| <= 3u(||q|| + ||o||),
+// e_q is a float sum of non-negative terms (relative
+// error <= (Dc+8)u), and the float distance of the exact phase is >= exact*(1 - (D+8)u).  All of
+// these are covered by the relative margin m = 4(Dc+32)u and the absolute slack
+// e_q(1+m) + 8u(||q|| + ||o||) + e_max used in threshold().
+// ---------------------------------------------------------------------------------------------
+constexpr int kPsHeader = 8;  // params: [0] s  [1] 1/s  [2] e_max  [3] ||o||  [4] valid  [8..] o_d
+struct NoPrescreen {
+  static constexpr bool enabled = false;
+};
+
+template <int LPR_, int NCH_>
+struct Prescreen {
+  static constexpr bool enabled = true;
+  static constexpr int LPR = LPR_;
+  static constexpr int NCH = NCH_;
+  static constexpr int ROWS = kWave / LPR;
+
+  const uint8_t* codes;
+  uint32_t Dc;  // code row length (multiple of 16)
+  int g;
+  uint4 qc[NCH];  // codes of the query for this lane's dimensions
+  uint32_t qq;    // sum of their squares
+  float inv_s, slack, m;
+
+  GGNN_DEV bool chunk_valid(int c) const
+  {
+    return static_cast<uint32_t>((c * LPR + g) * 16) < Dc;
+  }
+  GGNN_DEV const uint8_t* row_ptr(int k) const
+  {
+    return codes + static_cast<size_t>(static_cast<uint32_t>(k)) * Dc;
+  }
+  GGNN_DEV uint4 load_chunk(const uint8_t* row, int c) const
+  {
+    return *reinterpret_cast<const uint4*>(row + (c * LPR + g) * 16);
+  }
+
+  // D: float row length of the query (multiple of 4, <= Dc)
+  GGNN_DEV void load(const uint8_t* codes_, const float* params, uint32_t Dc_, const float* qrow,
+                     uint32_t D)
+  {
+    codes = codes_;
+    Dc = Dc_;
+    g = threadIdx.x % LPR;
+    inv_s = params[1];
+    const float* offs = params + kPsHeader;
+    float qs = 0.f, eq = 0.f;
+    qq = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint32_t d0 = static_cast<uint32_t>((c * LPR + g) * 16);
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), ov = qv;
+        if (d0 + 4 * j < D) {
+          qv = *reinterpret_cast<const float4*>(qrow + d0 + 4 * j);
+          ov = *reinterpret_cast<const float4*>(offs + d0 + 4 * j);
+        }
+        const float qe[4] = {qv.x, qv.y, qv.z, qv.w};
+        const float oe[4] = {ov.x, ov.y, ov.z, ov.w};
+        w[j] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = (qe[e] - oe[e]) * inv_s;
+          const float code = fminf(fmaxf(rintf(t), 0.f), 255.f);
+          const float diff = t - code;
+          eq = fmaf(diff, diff, eq);
+          qs = fmaf(qe[e], qe[e], qs);
+          w[j] |= static_cast<uint32_t>(code) << (8 * e);
+        }
+        qq = __builtin_amdgcn_udot4(w[j], w[j], qq, false);
+      }
+      qc[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    constexpr float u = 5.9604645e-8f;  // 2^-24
+    m = 4.f * static_cast<float>(Dc + 32) * u;
+    const float q_norm = sqrtf(group_sum<LPR>(qs));
+    const float e_q = params[0] * sqrtf(group_sum<LPR>(eq)) * (1.f + m);
+    slack = e_q + 8.f * u * (q_norm + params[3]) + params[2];
+  }
+
+  // sum (cq - c)^2 over this lane's chunks of one code row (exact)
+  GGNN_DEV float partial(const uint4 (&v)[NCH]) const
+  {
+    uint32_t ab = 0, bb = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      ab = __builtin_amdgcn_udot4(v[c].x, qc[c].x, ab, false);
+      ab = __builtin_amdgcn_udot4(v[c].y, qc[c].y, ab, false);
+      ab = __builtin_amdgcn_udot4(v[c].z, qc[c].z, ab, false);
+      ab = __builtin_amdgcn_udot4(v[c].w, qc[c].w, ab, false);
+      bb = __builtin_amdgcn_udot4(v[c].x, v[c].x, bb, false);
+      bb = __builtin_amdgcn_udot4(v[c].y, v[c].y, bb, false);
+      bb = __builtin_amdgcn_udot4(v[c].z, v[c].z, bb, false);
+      bb = __builtin_amdgcn_udot4(v[c].w, v[c].w, bb, false);
+    }
+    return static_cast<float>((qq + bb) - 2u * ab);
+  }
+
+  // a candidate with group-summed S >= threshold(crit) has a float distance >= crit
+  GGNN_DEV float threshold(float crit) const
+  {
+    if (!(crit < inf_f()))
+      return inf_f();
+    float t = sqrtf(crit) * (1.f + m) + slack;
+    t = t * inv_s * (1.f + m);
+    return t * t * (1.f + m);
+  }
+};
+
+// Drops the candidates of lds.ckeys[0,nsurv) whose lower bound reaches the criteria; the others
+// are compacted in place (order kept).  Returns their number.
+template <class PS>
+GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s_thr)
+{
+  constexpr int STEPS = StepsOf<PS::LPR, PS::NCH>::value;
+  constexpr int ROWS = PS::ROWS;
+  const int lane = threadIdx.x;
+  const int grp = lane / PS::LPR;
+  int npass = 0;
+  for (int s0 = 0; s0 < nsurv; s0 += ROWS * STEPS) {
+    uint4 v[STEPS][PS::NCH];
+    int kk[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int r = s0 + s * ROWS + grp;
+      const bool valid = r < nsurv;
+      kk[s] = valid ? lds.ckeys[r] : kEmptyKey;
+      const uint8_t* row = ps.row_ptr(valid ? kk[s] : 0);
+#pragma unroll
+      for (int c = 0; c < PS::NCH; ++c) {
+        v[s][c] = make_uint4(0u, 0u, 0u, 0u);
+        if (valid && ps.chunk_valid(c))
+          v[s][c] = ps.load_chunk(row, c);
+      }
+    }
+    __syncthreads();  // all keys of this round are in registers before the in-place compaction
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s0 + s * ROWS >= nsurv)
+        break;
+      const float S = group_sum<PS::LPR>(ps.partial(v[s]));
+      const bool pass = (kk[s] != kEmptyKey) && (ps.g == 0) && !(S >= s_thr);
+      const unsigned long long pm = __ballot(pass);
+      if (pass)
+        lds.ckeys[npass + __popcll(pm & ((1ull << lane) - 1ull))] = kk[s];
+      npass += __popcll(pm);
+    }
+  }
+  return npass;
+}
+
 // fetch(): simple_knn_cache.cuh:241-289.  cand: lane j (<32) holds candidate key j or EMPTY.
-// Returns the number of distance evaluations.
-template <int MODE, bool FILTER, class SL, class DE>
+// Returns the number of distance evaluations (of the reference: pre-screened candidates count);
+// rows.x / rows.y are advanced by the numbers of float / code rows actually read.
+template <int MODE, bool FILTER, class SL, class DE, class PS>
 GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
-                   const int32_t* translation)
+                   const int32_t* translation, const PS& ps, uint2& rows)
 {
   const int lane = threadIdx.x;
   cand = __shfl(cand, lane & 31);
@@ -701,10 +883,25 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
   if (lane < 32 && cand != kEmptyKey)
     lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
   __syncthreads();
-  compute_distances<MODE>(de, lds, nsurv, translation);
+  int neval = nsurv;
+  if constexpr (PS::enabled) {
+    const float s_thr = ps.threshold(sl.criteria());
+    if (s_thr < inf_f()) {
+      neval = prescreen_pass(ps, lds, nsurv, s_thr);
+      rows.y += nsurv;
+      if (neval == 0)
+        return nsurv;
+      __syncthreads();
+    }
+  }
+  // after the pre-screen only a handful of candidates are left: fewer rows in flight, fewer VGPRs
+  constexpr int kSteps = StepsOf<DE::LPR, DE::NCH>::value;
+  compute_distances<MODE, DE, (PS::enabled && kSteps > 2) ? 2 : kSteps>(de, lds, neval,
+                                                                        translation);
+  rows.x += neval;
   __syncthreads();
-  const float cd = lane < nsurv ? lds.cd0[lane] : inf_f();
-  const int ck = lane < nsurv ? lds.ckeys[lane] : kEmptyKey;
+  const float cd = lane < neval ? lds.cd0[lane] : inf_f();
+  const int ck = lane < neval ? lds.ckeys[lane] : kEmptyKey;
   // criteria() never increases during a fetch, so candidates failing it now fail it later
   unsigned long long m = __ballot(cd < sl.criteria());
   while (m) {
@@ -716,6 +913,13 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
       sl.push(k, d);
   }
   return nsurv;
+}
+template <int MODE, bool FILTER, class SL, class DE>
+GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
+                   const int32_t* translation)
+{
+  uint2 rows = make_uint2(0u, 0u);
+  return fetch<MODE, FILTER>(sl, de, lds, cand, translation, NoPrescreen{}, rows);
 }
 
 // block-size / chunk configuration by dimension and element type (host side)

@@ -129,6 +129,13 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
  * distance evaluations and of successful pops; used for the roofline figure. */
 ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop);
 ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
+/* rows the last ggnn_query read for those evaluations (needs collect_counters): float rows
+ * (4*D bytes each) and, with the pre-screen, 8-bit code rows (D rounded up to 16 bytes each). */
+ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows);
+/* Exact pre-screen of the float32 / Euclidean query kernel (no reference counterpart; results
+ * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
+ * environment variable GGNN_PRESCREEN=0 turns the default off. */
+ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable);
 /* nanobind.cu:151 set_log_level */
 void ggnn_set_log_level(int level);
 
@@ -154,6 +161,39 @@ ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, u
                           uint32_t max_iterations, ggnn_measure measure,
                           uint32_t shards_per_gpu, uint32_t on_gpu_shard, int32_t* ids,
                           float* dists, uint32_t* n_dist, uint32_t* n_pop, void* stream);
+
+/* Pre-screen copy of a float32 base (no reference counterpart; an exact pruning aid of
+ * query_layer.cu:69-77 / simple_knn_cache.cuh:268-286): every row is stored a second time as
+ * 8-bit codes c with x^_d = o_d + s*c_d plus a bound e_max >= max_rows ||x - x^||.  During a
+ * Euclidean float32 query a candidate whose lower bound (||q - x^|| - e_max)^2 already reaches
+ * the criteria is dropped without reading its float row -- exactly the candidates the reference
+ * evaluates and then discards -- so ids, distances and counters do not change.
+ * code_dim = D rounded up to 16; codes [N_base x code_dim] bytes; params [param_floats] floats
+ * ([0] s, [1] 1/s, [2] e_max, [3] ||o||, [4] usable (0 when the data holds non-finite values),
+ * [5..7] internal, [8..] o_d); scratch [scratch_floats] floats.  D must be a multiple of 4. */
+ggnn_status ggnn_prescreen_sizes(uint32_t D, uint32_t* code_dim, size_t* param_floats,
+                                 size_t* scratch_floats);
+ggnn_status ggnn_op_prescreen_encode(const float* base, uint32_t N_base, uint32_t D,
+                                     uint8_t* codes, float* params, float* scratch, void* stream);
+/* Validation probe: for query n and candidate cand[n*M+j], reject[n*M+j] = 1 iff the pre-screen
+ * would drop the candidate at criteria crit[n*M+j]; s_out (optional) receives the coded squared
+ * distance in code units.  A correct bound never rejects at a criteria above the float
+ * distance of the pair. */
+ggnn_status ggnn_op_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
+                                    const float* query, uint32_t Nq, const int32_t* cand,
+                                    uint32_t M, const float* crit, int32_t* reject, float* s_out,
+                                    void* stream);
+/* ggnn_op_query for float32 / Euclidean with the pre-screen copy (params[4] must be 1).
+ * n_rows: optional [Nq x 2], float rows and code rows read per query. */
+ggnn_status ggnn_op_query_prescreened(const float* base, uint32_t N_base, uint32_t D,
+                                      const uint8_t* codes, const float* params,
+                                      const float* query, uint32_t Nq, const int32_t* graph0,
+                                      uint32_t KBuild, const int32_t* start, uint32_t num_start,
+                                      const float* nn1_stats, uint32_t k_query, float tau_query,
+                                      uint32_t max_iterations, uint32_t shards_per_gpu,
+                                      uint32_t on_gpu_shard, int32_t* ids, float* dists,
+                                      uint32_t* n_dist, uint32_t* n_pop, uint32_t* n_rows,
+                                      void* stream);
 
 /* QueryKernels::bruteForceQuery  query_kernels.cu:188-264 -> bf_query_layer.cu:39-65 */
 ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,

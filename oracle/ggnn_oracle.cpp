@@ -32,6 +32,7 @@ double g_margin_min = std::numeric_limits<double>::infinity();
 // bench baseline only: plain 8-accumulator loops instead of the thread/tree emulation
 // (identical results on integer-valued data, where every summation order is exact)
 int g_fast_distance = 0;
+std::atomic<uint64_t> g_accept_total{0};
 
 // include/ggnn/base/def.h:37-56
 inline uint32_t bit_ceil_u32(uint32_t v)
@@ -125,6 +126,7 @@ struct DistCalc {
   float q_norm{0.f};           // r_query_norm (thread 0)
   std::vector<float> pa, pb;   // per-thread partials
   uint64_t n_calls{0};
+  uint64_t n_accepted{0};  // distance evaluations that passed the criteria (statistics only)
 
   DistCalc(const BaseView& b, int measure_, uint32_t block_, uint32_t items_)
       : base(b), measure(measure_), block(block_), items(items_), q(b.D), pa(block_), pb(block_)
@@ -460,8 +462,10 @@ void cache_fetch(Cache& c, DistCalc& dc, int32_t* keys, const int32_t* translati
       continue;
     const int32_t other_m = translation ? translation[other_n] : other_n;
     const float d = dc.distance((uint64_t)other_m);
-    if (d < c.criteria())
+    if (d < c.criteria()) {
+      ++dc.n_accepted;
       c.push(other_n, d);
+    }
   }
 }
 
@@ -585,6 +589,11 @@ extern "C" {
 void orc_set_fast_distance(int enable)
 {
   g_fast_distance = enable;
+}
+
+uint64_t orc_accept_total(int reset)
+{
+  return reset ? g_accept_total.exchange(0) : g_accept_total.load();
 }
 
 void orc_margin_reset()
@@ -783,6 +792,7 @@ void orc_query(const void* base, uint32_t N, uint32_t D, int dtype, const void* 
       n_dist[n] = (uint32_t)dc.n_calls;
     if (n_pop)
       n_pop[n] = pops;
+    g_accept_total.fetch_add(dc.n_accepted);
   });
 }
 

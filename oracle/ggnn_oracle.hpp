@@ -142,6 +142,8 @@ void orc_wave_model_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, float
 // bench cpu_baseline only: compute distances with plain multi-accumulator loops (a fair scalar/
 // SIMD port) instead of the thread-by-thread emulation.  Default off (parity tests).
 void orc_set_fast_distance(int enable);
+// statistics: number of distance evaluations accepted (d < criteria) by orc_query since reset
+uint64_t orc_accept_total(int reset);
 void orc_margin_reset();
 double orc_margin_min();
 

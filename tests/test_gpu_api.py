@@ -292,3 +292,26 @@ def test_uint8_and_cosine_through_the_api(orc):
             np.testing.assert_allclose(gd.numpy(), o_gd, rtol=1e-4, atol=1e-7)
         ev = ggnn.Evaluator(base, q, gt, 10, measure).evaluate_results(ids)
         assert ev.c_k_query > 0.9, repr(ev)
+
+
+def test_prescreen_toggle_gives_identical_results():
+    # one graph (construction is not run-to-run deterministic: sym uses atomics, as in the
+    # reference), queried with the pre-screen on, off and on again
+    import ggnn_amd as ggnn
+    rng = np.random.default_rng(5)
+    centres = rng.normal(size=(16, 128)) * 3
+    base = (centres[rng.integers(0, 16, 6000)] + rng.normal(size=(6000, 128))).astype(np.float32)
+    q = (centres[rng.integers(0, 16, 300)] + rng.normal(size=(300, 128))).astype(np.float32)
+    g = ggnn.GGNN()
+    g.set_collect_counters(True)
+    g.set_base(base)
+    g.build(24, 0.5, 1)
+    out = []
+    for enable in (True, False, True):
+        g.set_prescreen(enable)
+        ids, d = g.query(q, 10, 0.8, 200)
+        out.append((np.asarray(ids), np.asarray(d), g.last_query_counters()))
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0])
+        assert np.array_equal(out[0][1], o[1])
+        assert out[0][2] == o[2]

@@ -572,3 +572,109 @@ def test_two_dimensional_grids_beyond_2_20_blocks(ops, orc):
     u = ops.uniform(300_000_000, 7, 0)          # 1.17M blocks of 256 threads
     tail = u[-1_000_000:].cpu().numpy()
     assert tail.min() > 0.0 and tail.max() <= 1.0 and abs(tail.mean() - 0.5) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------
+# exact pre-screen of the float32 / Euclidean query (extension; must not change any result)
+# ---------------------------------------------------------------------------------------------
+def _quarter_data(N, D, seed):
+    """multiples of 1/4 in [0, 256): every fp32 sum is exact, yet the 8-bit coding is lossy"""
+    return (np.random.default_rng(seed).integers(0, 1024, (N, D)) / 4.0).astype(np.float32)
+
+
+def _clustered(N, D, seed, offset=0.0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(32, D)) * 4.0
+    x = centres[rng.integers(0, 32, N)] + rng.normal(size=(N, D))
+    return (x * scale + offset).astype(np.float32)
+
+
+def test_prescreen_sizes_and_lossless_integers(ops):
+    base = dev(make_int_data(3000, 128, 5))
+    assert ops.prescreen_sizes(128)[0] == 128 and ops.prescreen_sizes(100)[0] == 112
+    codes, params = ops.prescreen_encode(base)
+    p = params.cpu().numpy()
+    assert p[0] == 1.0 and p[1] == 1.0 and p[2] == 0.0 and p[4] == 1.0
+    offs = p[8:8 + 128]
+    assert np.array_equal(codes.cpu().numpy().astype(np.float32) + offs, base.cpu().numpy())
+
+
+def test_prescreen_refuses_non_finite(ops):
+    base = make_uni_data(1000, 64, 3)
+    base[17, 5] = np.inf
+    _, params = ops.prescreen_encode(dev(base))
+    assert params.cpu().numpy()[4] == 0.0
+    base[17, 5] = np.nan
+    _, params = ops.prescreen_encode(dev(base))
+    assert params.cpu().numpy()[4] == 0.0
+
+
+@pytest.mark.parametrize("maker,D", [(_quarter_data, 128), (_clustered, 128), (_clustered, 100),
+                                     (make_uni_data, 64), (_clustered, 256), (_clustered, 960),
+                                     (make_int_data, 2048)])
+def test_prescreen_bound_never_exceeds_the_float_distance(ops, orc, maker, D):
+    N, Nq, M = 4000, 48, 96
+    base, q = maker(N, D, 71), maker(Nq, D, 72)
+    Dp = (D + 3) // 4 * 4
+    if Dp != D:
+        base = np.pad(base, ((0, 0), (0, Dp - D)))
+        q = np.pad(q, ((0, 0), (0, Dp - D)))
+    codes, params = ops.prescreen_encode(dev(base))
+    assert params.cpu().numpy()[4] == 1.0
+    rng = np.random.default_rng(73)
+    cand = rng.integers(0, N, (Nq, M)).astype(np.int32)
+    # The reference pushes iff d < criteria, so the pre-screen must not reject at any criteria
+    # above the float32 distance d.  A float32 evaluation (any summation order) lies within
+    # (D+8) * 2^-24 of the exact value, so test at a criteria below every possible evaluation.
+    d = ((q[:, None, :].astype(np.float64) - base[cand].astype(np.float64)) ** 2).sum(-1)
+    d32 = d.astype(np.float32)
+    just_above = (d * (1.0 - 3.0 * (Dp + 8) * 2.0 ** -24)).astype(np.float32)
+    rej, _ = ops.prescreen_probe(codes, params, dev(q), dev(cand), dev(just_above))
+    assert int(rej.sum()) == 0
+    rej, _ = ops.prescreen_probe(codes, params, dev(q), dev(cand),
+                                 dev(np.full_like(d32, np.inf)))
+    assert int(rej.sum()) == 0
+    # and it is useful: at half the true distance nearly everything is rejected
+    rej, _ = ops.prescreen_probe(codes, params, dev(q), dev(cand), dev(d32 * np.float32(0.5)))
+    assert rej.float().mean().item() > 0.9
+
+
+@pytest.mark.parametrize("maker,kw", [(_quarter_data, {}), (make_int_data, {}), (_clustered, {}),
+                                      (_clustered, dict(offset=1000.0)),
+                                      (_clustered, dict(scale=1e-3, offset=-5.0)),
+                                      (make_uni_data, {})])
+@pytest.mark.parametrize("D", [128, 72])
+def test_query_prescreened_equals_plain_query(ops, orc, maker, kw, D):
+    N, K = 3000, 24
+    base, q = maker(N, D, 81, **kw), maker(200, D, 82, **kw)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 1, rng=orc.make_rng(N, 7))
+    start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
+    b, qq, g0, st, ss = dev(base), dev(q), dev(graph[:N]), dev(start), dev(stats)
+    ps = ops.prescreen_encode(b)
+    assert ps[1].cpu().numpy()[4] == 1.0
+    for kq, tau, iters in ((10, 0.6, 200), (1, 0.9, 100), (100, 0.5, 400), (300, 0.4, 512)):
+        plain = ops.query(b, qq, g0, st, ss, kq, tau, iters, counters=True)
+        fast = ops.query(b, qq, g0, st, ss, kq, tau, iters, counters=True, prescreen=ps)
+        for x, y in zip(plain, fast):
+            assert torch.equal(x, y)
+    if maker in (_quarter_data, make_int_data):
+        o = orc.query(base, q, graph[:N], start, stats, 10, 0.6, 200, counters=True)
+        fast = ops.query(b, qq, g0, st, ss, 10, 0.6, 200, counters=True, prescreen=ps)
+        assert np.array_equal(fast[0].cpu().numpy(), o[0])
+        assert np.array_equal(fast[1].cpu().numpy(), o[1])
+        assert np.array_equal(fast[2].cpu().numpy().astype(np.uint32), o[2])
+        assert np.array_equal(fast[3].cpu().numpy().astype(np.uint32), o[3])
+
+
+@pytest.mark.parametrize("D", [256, 960])
+def test_query_prescreened_wide_rows(ops, orc, D):
+    N, K = 2000, 24
+    base, q = _clustered(N, D, 91), _clustered(64, D, 92)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, rng=orc.make_rng(N, 8))
+    start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
+    b, qq, g0, st, ss = dev(base), dev(q), dev(graph[:N]), dev(start), dev(stats)
+    ps = ops.prescreen_encode(b)
+    plain = ops.query(b, qq, g0, st, ss, 10, 0.7, 200, counters=True)
+    fast = ops.query(b, qq, g0, st, ss, 10, 0.7, 200, counters=True, prescreen=ps)
+    for x, y in zip(plain, fast):
+        assert torch.equal(x, y)
