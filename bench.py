@@ -107,7 +107,7 @@ def workload_string(args):
             f"tau_query={args.tau_query}, max_iterations={args.max_iters}")
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, prescreened):
     """HBM bytes per query_kernel launch from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/*_pmc_hbm.json), corrected
     as MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 on gfx950 for 16 B/lane loads).
@@ -122,9 +122,12 @@ def pmc_traffic(args):
         return None  # the committed counters were collected on a different workload
     pmc = doc["kernels"]
     for name, c in pmc.items():
-        if "query_kernel" in name and "bf_query" not in name and "FETCH_SIZE" in c:
-            wr = c.get("WRITE_SIZE", {"avg_kb": 0.0})["avg_kb"]
-            return 2.0 * c["FETCH_SIZE"]["avg_kb"] * 1024.0 + wr * 1024.0
+        if "query_kernel" not in name or "bf_query" in name or "FETCH_SIZE" not in c:
+            continue
+        if ("NoPrescreen" in name) == prescreened:
+            continue  # the variant of the kernel this figure is about
+        wr = c.get("WRITE_SIZE", {"avg_kb": 0.0})["avg_kb"]
+        return 2.0 * c["FETCH_SIZE"]["avg_kb"] * 1024.0 + wr * 1024.0
     return None
 
 
@@ -227,6 +230,21 @@ def main():
     rows = eng.last_query_rows_read()
     eng.set_collect_counters(False)
 
+    # the same kernel without the pre-screen (untimed extra runs): the HBM-bound form of the
+    # traversal, every distance evaluation reads its 4D-byte row
+    plain_ms = None
+    if rows["code_rows"] > 0:
+        eng.set_prescreen(False)
+        plain = []
+        for i in range(2 + min(args.steps, 10)):
+            ids_plain, dists_plain = step()
+            if i >= 2:
+                plain.append(eng.last_timing_ms()["query_ms"])
+        eng.set_prescreen(True)
+        plain_ms = float(np.mean(plain))
+        if not (torch.equal(ids_plain, ids) and torch.equal(dists_plain, dists)):
+            raise RuntimeError("pre-screened and plain query results differ")
+
     if rank == 0:
         nq, d, k = args.n_query, args.dim, args.k
         ms_per_step = elapsed / args.steps * 1000.0
@@ -280,13 +298,21 @@ def main():
             "code_rows_per_query": rows["code_rows"] / nq,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args),
+                         "traffic": pmc_traffic(args, prescreened),
                          "kernel": ("query_kernel<float,16,2,1,L2,Prescreen<8,1>>" if prescreened
                                     else "query_kernel<float,16,2,1,L2,NoPrescreen>"),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "reference_algorithm_bytes_per_launch": ref_bytes,
                          "reference_algorithm_equivalent_GBs":
                              ref_bytes / (avg_kernel_ms * 1e-3) / 1e9,
+                         "without_prescreen": (None if plain_ms is None else {
+                             "kernel": "query_kernel<float,16,2,1,L2,NoPrescreen>",
+                             "query_kernel_ms": plain_ms,
+                             "queries_per_s": nq / (plain_ms * 1e-3),
+                             "achieved": ref_bytes / (plain_ms * 1e-3) / 1e9,
+                             "frac": ref_bytes / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": pmc_traffic(args, False),
+                             "results": "bit-identical to the pre-screened run"}),
                          "note": ("algorithmic bytes of this kernel (code rows + float rows of "
                                   "the candidates that pass the exact pre-screen) / HIP-event "
                                   "kernel time. The pre-screen removes ~%.0f %% of the bytes the "

@@ -85,17 +85,21 @@ SIGNATURES = {
     "ggnn_query_sizing": (_int, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_op_query": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32,
                              _f32, _u32, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
-    "ggnn_prescreen_sizes": (_int, [_u32, C.POINTER(_u32), C.POINTER(_sz), C.POINTER(_sz)]),
-    "ggnn_op_prescreen_encode": (_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
-    "ggnn_op_prescreen_probe": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "ggnn_prescreen_sizes": (_int, [_u32, _u32, _int, C.POINTER(_u32), C.POINTER(_sz),
+                                    C.POINTER(_sz)]),
+    "ggnn_op_prescreen_encode": (_int, [_vp, _u32, _u32, _int, _vp, _vp, _vp, _vp]),
+    "ggnn_op_prescreen_probe": (_int, [_vp, _vp, _u32, _int, _vp, _u32, _vp, _u32, _vp, _vp, _vp,
+                                       _vp]),
     "ggnn_op_query_prescreened": (_int, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _u32,
-                                         _vp, _u32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp,
-                                         _vp, _vp]),
+                                         _vp, _u32, _f32, _u32, _int, _u32, _u32, _vp, _vp, _vp,
+                                         _vp, _vp, _vp]),
     "ggnn_op_bf_query": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp, _vp]),
     "ggnn_op_top": (_int, [_vp, _int, _u32, _int, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp,
                            _vp]),
     "ggnn_op_merge": (_int, [_vp, _int, _int, _cfgp, _vp, _vp, _vp, _vp, _f32, _u32, _u32, _vp,
                              _vp, _vp, _vp]),
+    "ggnn_op_merge_prescreened": (_int, [_vp, _vp, _vp, _int, _cfgp, _vp, _vp, _vp, _vp, _f32, _u32,
+                                         _u32, _vp, _vp, _vp, _vp]),
     "ggnn_op_select": (_int, [_cfgp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "ggnn_op_uniform": (_int, [_vp, _u32, _u64, _u64, _vp]),
     "ggnn_op_sym": (_int, [_vp, _int, _int, _u32, _u32, _vp, _vp, _u32, _vp, _f32, _vp, _vp, _u32,

@@ -106,7 +106,7 @@ struct QueryLaunch {
   float* dists;
   uint32_t* n_dist;
   uint32_t* n_pop;
-  // optional pre-screen copy of the base (launch_prescreen_encode); ignored unless float32 + L2
+  // optional pre-screen copy of the base (launch_prescreen_encode, same measure); ignored unless float32
   const uint8_t* ps_codes{nullptr};
   const float* ps_params{nullptr};
   uint32_t ps_Dc{0};
@@ -114,18 +114,19 @@ struct QueryLaunch {
 };
 void launch_query(const QueryLaunch& a, hipStream_t stream);
 
-// 8-bit pre-screen copy of a float32 base (prescreen.hip): codes [N x Dc], Dc = D rounded up to
-// 16; params [prescreen_param_floats(D)] floats; scratch [prescreen_scratch_floats(D)] floats.
+// 8-bit pre-screen copy of a float32 base for one distance measure (prescreen.hip): codes
+// [N x Dc], Dc = D rounded up to 16; params [prescreen_param_floats(D)] floats; scratch
+// [prescreen_scratch_floats(N, D, measure)] floats.
 constexpr int kPsHeaderFloats = 8;
 inline uint32_t prescreen_code_dim(uint32_t D) { return (D + 15u) / 16u * 16u; }
 size_t prescreen_param_floats(uint32_t D);
-size_t prescreen_scratch_floats(uint32_t D);
-void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, uint8_t* codes,
-                             float* params, float* scratch, hipStream_t stream);
+size_t prescreen_scratch_floats(uint32_t N, uint32_t D, ggnn_measure measure);
+void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, ggnn_measure measure,
+                             uint8_t* codes, float* params, float* scratch, hipStream_t stream);
 void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
-                            const float* query, uint32_t Nq, const int32_t* cand, uint32_t M,
-                            const float* crit, int32_t* reject, float* s_out,
-                            hipStream_t stream);
+                            ggnn_measure measure, const float* query, uint32_t Nq,
+                            const int32_t* cand, uint32_t M, const float* crit, int32_t* reject,
+                            float* s_out, hipStream_t stream);
 
 struct BfLaunch {
   const void* base;
@@ -165,6 +166,10 @@ struct MergeLaunch {
   int32_t* graph_buffer;
   float* nn1_dist_buffer;
   uint32_t* n_dist;
+  // optional pre-screen copy of the base (launch_prescreen_encode, same measure); ignored unless float32
+  const uint8_t* ps_codes{nullptr};
+  const float* ps_params{nullptr};
+  uint32_t ps_Dc{0};
 };
 void launch_merge(const MergeLaunch& a, hipStream_t stream);
 

@@ -108,10 +108,12 @@ struct Shard {
   int32_t* selection{nullptr};
   float* nn1_stats{nullptr};
   bool ready{false};
-  // 8-bit pre-screen copy of this shard's rows (prescreen.hip), made at the first Euclidean
-  // float32 query: 0 = not attempted, 1 = usable, -1 = data not codable (non-finite values)
+  // 8-bit pre-screen copy of this shard's rows (prescreen.hip) for ps_measure, made when a
+  // float32 build or query first needs it: 0 = not attempted, 1 = usable, -1 = data not codable
+  // (non-finite values)
   DeviceBuffer ps_codes, ps_params;
   int ps_state{0};
+  ggnn_measure ps_measure{GGNN_EUCLIDEAN};
 
   static size_t pool_bytes(const ggnn_graph_config& c)
   {
@@ -361,6 +363,9 @@ struct ggnn_handle {
     uint64_t rng_calls = static_cast<uint64_t>(ctx.first_shard) << 16;
 
     for (uint32_t si = 0; si < ctx.shards.size(); ++si) {
+      // the pre-screen copy serves the merge kernel too (made outside the timed region: it
+      // depends on the base only and is kept for the queries)
+      const bool use_ps = ensure_prescreen(ctx, si, measure);
       Shard& sh = ctx.shards[si];
       const void* base = shard_base(ctx, si);
       EventTimer timer(stream);
@@ -394,6 +399,11 @@ struct ggnn_handle {
                         graph_buffer.as<int32_t>(),
                         nn1_dist.as<float>(),
                         nullptr};
+          if (use_ps) {
+            m.ps_codes = sh.ps_codes.as<uint8_t>();
+            m.ps_params = sh.ps_params.as<float>();
+            m.ps_Dc = prescreen_code_dim(pad_D);
+          }
           launch_merge(m, stream);
           GGNN_HIP_CHECK(hipMemcpyAsync(layer_graph(btm), graph_buffer.p,
                                         static_cast<size_t>(cfg.Ns[btm]) * K * 4,
@@ -528,14 +538,16 @@ struct ggnn_handle {
   bool ensure_prescreen(DeviceCtx& ctx, uint32_t si, ggnn_measure measure)
   {
     Shard& sh = ctx.shards[si];
-    if (!prescreen || base_dtype != GGNN_F32 || measure != GGNN_EUCLIDEAN || pad_D < 64)
+    if (!prescreen || base_dtype != GGNN_F32 || pad_D < 64)
       return false;
+    if (sh.ps_state != 0 && sh.ps_measure != measure)
+      sh.ps_state = 0;  // the codes belong to the other measure: code again
     if (sh.ps_state == 0) {
       const uint32_t Dc = prescreen_code_dim(pad_D);
       sh.ps_codes.alloc(static_cast<size_t>(cfg.N) * Dc);
       sh.ps_params.alloc(prescreen_param_floats(pad_D) * 4);
-      DeviceBuffer scratch(prescreen_scratch_floats(pad_D) * 4);
-      launch_prescreen_encode(static_cast<const float*>(shard_base(ctx, si)), cfg.N, pad_D,
+      DeviceBuffer scratch(prescreen_scratch_floats(cfg.N, pad_D, measure) * 4);
+      launch_prescreen_encode(static_cast<const float*>(shard_base(ctx, si)), cfg.N, pad_D, measure,
                               sh.ps_codes.as<uint8_t>(), sh.ps_params.as<float>(),
                               scratch.as<float>(), ctx.stream);
       float header[kPsHeaderFloats];
@@ -543,9 +555,10 @@ struct ggnn_handle {
                                     ctx.stream));
       GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
       sh.ps_state = header[4] != 0.f ? 1 : -1;
-      GGNN_LOG(1, "[GPU: %d] pre-screen copy of part %u: scale %g, max coding error %g%s",
-               ctx.device, sh.global_id, header[0], header[2],
-               sh.ps_state > 0 ? "" : " (unusable, disabled)");
+      sh.ps_measure = measure;
+      GGNN_LOG(1, "[GPU: %d] pre-screen copy of part %u (%s): scale %g, max coding error %g%s",
+               ctx.device, sh.global_id, measure == GGNN_EUCLIDEAN ? "L2" : "cosine", header[0],
+               header[2], sh.ps_state > 0 ? "" : " (unusable, disabled)");
       if (sh.ps_state < 0) {
         sh.ps_codes.release();
         sh.ps_params.release();
@@ -1113,8 +1126,8 @@ ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, u
   });
 }
 
-ggnn_status ggnn_prescreen_sizes(uint32_t D, uint32_t* code_dim, size_t* param_floats,
-                                 size_t* scratch_floats)
+ggnn_status ggnn_prescreen_sizes(uint32_t N_base, uint32_t D, ggnn_measure measure,
+                                 uint32_t* code_dim, size_t* param_floats, size_t* scratch_floats)
 {
   return guarded(nullptr, [&] {
     GGNN_REQUIRE(D >= 1 && D <= 4096 && D % 4 == 0, GGNN_INVALID_ARGUMENT,
@@ -1124,26 +1137,27 @@ ggnn_status ggnn_prescreen_sizes(uint32_t D, uint32_t* code_dim, size_t* param_f
     if (param_floats)
       *param_floats = prescreen_param_floats(D);
     if (scratch_floats)
-      *scratch_floats = prescreen_scratch_floats(D);
+      *scratch_floats = prescreen_scratch_floats(N_base, D, measure);
   });
 }
 
 ggnn_status ggnn_op_prescreen_encode(const float* base, uint32_t N_base, uint32_t D,
-                                     uint8_t* codes, float* params, float* scratch, void* stream)
+                                     ggnn_measure measure, uint8_t* codes, float* params,
+                                     float* scratch, void* stream)
 {
   return guarded(nullptr, [&] {
-    launch_prescreen_encode(base, N_base, D, codes, params, scratch,
+    launch_prescreen_encode(base, N_base, D, measure, codes, params, scratch,
                             static_cast<hipStream_t>(stream));
   });
 }
 
 ggnn_status ggnn_op_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
-                                    const float* query, uint32_t Nq, const int32_t* cand,
-                                    uint32_t M, const float* crit, int32_t* reject, float* s_out,
-                                    void* stream)
+                                    ggnn_measure measure, const float* query, uint32_t Nq,
+                                    const int32_t* cand, uint32_t M, const float* crit,
+                                    int32_t* reject, float* s_out, void* stream)
 {
   return guarded(nullptr, [&] {
-    launch_prescreen_probe(codes, params, D, query, Nq, cand, M, crit, reject, s_out,
+    launch_prescreen_probe(codes, params, D, measure, query, Nq, cand, M, crit, reject, s_out,
                            static_cast<hipStream_t>(stream));
   });
 }
@@ -1153,16 +1167,16 @@ ggnn_status ggnn_op_query_prescreened(const float* base, uint32_t N_base, uint32
                                       const float* query, uint32_t Nq, const int32_t* graph0,
                                       uint32_t KBuild, const int32_t* start, uint32_t num_start,
                                       const float* nn1_stats, uint32_t k_query, float tau_query,
-                                      uint32_t max_iterations, uint32_t shards_per_gpu,
-                                      uint32_t on_gpu_shard, int32_t* ids, float* dists,
-                                      uint32_t* n_dist, uint32_t* n_pop, uint32_t* n_rows,
-                                      void* stream)
+                                      uint32_t max_iterations, ggnn_measure measure,
+                                      uint32_t shards_per_gpu, uint32_t on_gpu_shard, int32_t* ids,
+                                      float* dists, uint32_t* n_dist, uint32_t* n_pop,
+                                      uint32_t* n_rows, void* stream)
 {
   return guarded(nullptr, [&] {
     GGNN_REQUIRE(codes && params, GGNN_INVALID_ARGUMENT, "pre-screen buffers are null");
-    QueryLaunch q{base,      query,          GGNN_F32,       N_base,         D,         Nq,
-                  graph0,    KBuild,         start,          num_start,      nn1_stats, k_query,
-                  tau_query, max_iterations, GGNN_EUCLIDEAN, shards_per_gpu, on_gpu_shard, ids,
+    QueryLaunch q{base,      query,          GGNN_F32, N_base,         D,         Nq,
+                  graph0,    KBuild,         start,    num_start,      nn1_stats, k_query,
+                  tau_query, max_iterations, measure,  shards_per_gpu, on_gpu_shard, ids,
                   dists,     n_dist,         n_pop};
     q.ps_codes = codes;
     q.ps_params = params;
@@ -1206,6 +1220,28 @@ ggnn_status ggnn_op_merge(const void* base, ggnn_dtype dtype, ggnn_measure measu
     MergeLaunch m{base,      dtype,     measure,   *cfg,         graph_all,       translation_all,
                   selection_all, nn1_stats, tau_build, layer_top, layer_btm,      graph_buffer,
                   nn1_dist_buffer, n_dist};
+    launch_merge(m, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_merge_prescreened(const float* base, const uint8_t* codes, const float* params,
+                                      ggnn_measure measure, const ggnn_graph_config* cfg,
+                                      const int32_t* graph_all,
+                                      const int32_t* translation_all,
+                                      const int32_t* selection_all, const float* nn1_stats,
+                                      float tau_build, uint32_t layer_top, uint32_t layer_btm,
+                                      int32_t* graph_buffer, float* nn1_dist_buffer,
+                                      uint32_t* n_dist, void* stream)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(cfg != nullptr, GGNN_INVALID_ARGUMENT, "null graph config");
+    GGNN_REQUIRE(codes && params, GGNN_INVALID_ARGUMENT, "pre-screen buffers are null");
+    MergeLaunch m{base,          GGNN_F32,  measure,        *cfg,      graph_all, translation_all,
+                  selection_all, nn1_stats, tau_build,      layer_top, layer_btm, graph_buffer,
+                  nn1_dist_buffer, n_dist};
+    m.ps_codes = codes;
+    m.ps_params = params;
+    m.ps_Dc = prescreen_code_dim(cfg->D);
     launch_merge(m, static_cast<hipStream_t>(stream));
   });
 }

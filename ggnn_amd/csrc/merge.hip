@@ -18,6 +18,10 @@ struct MergeArgs {
   uint32_t D, KBuild, S, G, S0, S0_off, layer_top, layer_btm, sorted, N_btm;
   uint32_t Ns_off[kLayers], STs_off[kLayers];
   float tau;
+  // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
+  const uint8_t* ps_codes;
+  const float* ps_params;
+  uint32_t ps_Dc;
 };
 
 constexpr uint32_t kMergeCache = 256;      // merge_layer.cuh:44
@@ -29,7 +33,7 @@ uint32_t merge_sorted_size(uint32_t KBuild)
   return std::max(64u, next_multiple32(KBuild + 1 + 16));
 }
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE>
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -50,6 +54,14 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
 
   DistEngine<BaseT, LPR, NCH> de;
   de.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D);
+  // exact pre-screen (traversal.hpp): the point is coded like any query, which reproduces its
+  // stored codes and gives its own coding error
+  PSC ps;
+  if constexpr (PSC::enabled)
+    ps.load(a.ps_codes, a.ps_params, a.ps_Dc,
+            reinterpret_cast<const float*>(base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D),
+            a.D);
+  uint2 rows_read = make_uint2(0u, 0u);
 
   SortedList<R> sl;
   sl.init(K + 1, a.sorted, kMergeCache, xi, lds.known);
@@ -71,7 +83,8 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
       const int cand = (lane < (int)kKBlock && i + lane < a.S)
                            ? static_cast<int>(s_offset + i + lane)
                            : kEmptyKey;
-      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, a.translation_all + a.STs_off[a.layer_top]);
+      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, a.translation_all + a.STs_off[a.layer_top],
+                                     ps, rows_read);
     }
   }
 
@@ -82,7 +95,7 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
     const int32_t* tr = (!layer) ? nullptr : a.translation_all + a.STs_off[layer];
     if (layer == a.layer_btm) {
       const int cand = (lane == 0) ? n : kEmptyKey;
-      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, tr);
+      cnt_dist += fetch<MODE, false>(sl, de, lds, cand, tr, ps, rows_read);
     }
     for (uint32_t ite = 0; ite < kMergeIterations; ++ite) {
       const int anchor = sl.pop(sl.criteria(), lds.known);
@@ -92,7 +105,7 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
           a.graph_all + (static_cast<size_t>(a.Ns_off[layer]) + static_cast<uint32_t>(anchor)) * K;
       for (uint32_t j = 0; j < K; j += kKBlock) {
         const int cand = (lane < (int)kKBlock && j + lane < K) ? row[j + lane] : kEmptyKey;
-        cnt_dist += fetch<MODE, true>(sl, de, lds, cand, tr);
+        cnt_dist += fetch<MODE, true>(sl, de, lds, cand, tr, ps, rows_read);
       }
     }
   }
@@ -138,21 +151,40 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
     a.n_dist[un] = cnt_dist;
 }
 
-template <typename BaseT, int LPR, int NCH, int MODE>
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kMergeCache);
   if (args.sorted <= 64)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 256)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
+}
+
+template <typename BaseT, int LPR, int NCH>
+static void launch_merge_cfg(const MergeArgs& args, bool use_ps, ggnn_measure measure,
+                             hipStream_t stream)
+{
+  if constexpr (std::is_same<BaseT, float>::value) {
+    if (use_ps) {
+      if (measure == GGNN_EUCLIDEAN)
+        launch_merge_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH, kL2>::type>(args, stream);
+      else
+        launch_merge_r<BaseT, LPR, NCH, kCos, typename PsFor<LPR, NCH, kCos>::type>(args, stream);
+      return;
+    }
+  }
+  if (measure == GGNN_EUCLIDEAN)
+    launch_merge_r<BaseT, LPR, NCH, kL2, NoPrescreen>(args, stream);
+  else
+    launch_merge_r<BaseT, LPR, NCH, kCos, NoPrescreen>(args, stream);
 }
 
 void launch_merge(const MergeLaunch& a, hipStream_t stream)
@@ -189,13 +221,15 @@ void launch_merge(const MergeLaunch& a, hipStream_t stream)
   if (!args.N_btm)
     return;
 
-#define GGNN_LAUNCH_MERGE(T, LPR, NCH)                     \
-  do {                                                     \
-    if (a.measure == GGNN_EUCLIDEAN)                       \
-      launch_merge_r<T, LPR, NCH, kL2>(args, stream);      \
-    else                                                   \
-      launch_merge_r<T, LPR, NCH, kCos>(args, stream);     \
-  } while (0)
+  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
+  if (use_ps) {
+    GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(c.D), GGNN_INVALID_ARGUMENT,
+                 "pre-screen code rows must be D rounded up to 16");
+    args.ps_codes = a.ps_codes;
+    args.ps_params = a.ps_params;
+    args.ps_Dc = a.ps_Dc;
+  }
+#define GGNN_LAUNCH_MERGE(T, LPR, NCH) launch_merge_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, c.D, GGNN_LAUNCH_MERGE);
 #undef GGNN_LAUNCH_MERGE
   GGNN_HIP_CHECK(hipGetLastError());

@@ -7,6 +7,8 @@
 // is first tried as a power of two: integer (or dyadic) data with a range <= 255 s per dimension
 // (SIFT) is then coded without loss (e_max = 0).  Otherwise the rows are coded again with the
 // tightest scale, max range / 255.
+// For the cosine measure the rows are coded after normalisation to unit length (a zero row stays
+// zero); e_max then bounds the error against the exactly normalised row.
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -19,15 +21,18 @@ constexpr uint32_t kPsThreads = 256;
 // partial[b][0][d] = min, partial[b][1][d] = max over the rows b, b+B, ... ; flags[0] != 0 when
 // a non-finite value was seen
 __global__ void __launch_bounds__(kPsThreads)
-    ps_minmax_kernel(const float* base, uint32_t N, uint32_t D, uint32_t B, float* partial,
-                     uint32_t* flags)
+    ps_minmax_kernel(const float* base, uint32_t N, uint32_t D, uint32_t B, const float* inv_norm,
+                     float* partial, uint32_t* flags)
 {
   const uint32_t b = blockIdx.x;
   bool bad = false;
   for (uint32_t d = threadIdx.x; d < D; d += kPsThreads) {
     float mn = inf_f(), mx = -inf_f();
     for (uint64_t r = b; r < N; r += B) {
-      const float v = base[r * D + d];
+      float v = base[r * D + d];
+      bad |= !(fabsf(v) < inf_f());
+      if (inv_norm)
+        v *= inv_norm[r];
       bad |= !(fabsf(v) < inf_f());
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
@@ -42,7 +47,7 @@ __global__ void __launch_bounds__(kPsThreads)
 // one block: per-dimension offsets, the common scale, header of params
 __global__ void __launch_bounds__(kPsThreads)
     ps_finalize_kernel(const float* partial, const uint32_t* flags, uint32_t D, uint32_t Dc,
-                       uint32_t B, float* params)
+                       uint32_t B, int measure, float* params)
 {
   __shared__ float s_range[kPsThreads];
   __shared__ float s_osq[kPsThreads];
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(kPsThreads)
     params[4] = ok ? 1.f : 0.f;
     params[5] = range;  // for ps_retry_kernel
     params[6] = 1.f;    // coding pass wanted
-    params[7] = 0.f;
+    params[7] = static_cast<float>(measure);
   }
 }
 
@@ -105,10 +110,38 @@ __global__ void ps_retry_kernel(float* params)
     params[6] = 0.f;
 }
 
+// sum of squares of one row in double, lpr lanes per row; every lane of the row gets the total
+__device__ __forceinline__ double ps_row_norm2(const float* base, uint64_t row, uint32_t N,
+                                               uint32_t D, uint32_t lpr, uint32_t g)
+{
+  double acc = 0.0;
+  if (row < N) {
+    const float* x = base + row * D;
+    for (uint32_t d = g; d < D; d += lpr)
+      acc += static_cast<double>(x[d]) * static_cast<double>(x[d]);
+  }
+  for (uint32_t off = lpr / 2; off; off >>= 1)
+    acc += __shfl_xor(acc, off);
+  return acc;
+}
+
+// cosine: 1 / |x| per row in float (0 for a zero row), used by the range pass and the coder
+__global__ void __launch_bounds__(kPsThreads)
+    ps_inv_norm_kernel(const float* base, uint32_t N, uint32_t D, uint32_t lpr, float* inv_norm)
+{
+  const uint32_t rows_per_block = kPsThreads / lpr;
+  const uint64_t row = static_cast<uint64_t>(block_linear_index()) * rows_per_block +
+                       threadIdx.x / lpr;
+  const uint32_t g = threadIdx.x % lpr;
+  const double n2 = ps_row_norm2(base, row, N, D, lpr, g);
+  if (row < N && g == 0)
+    inv_norm[row] = n2 > 0.0 ? static_cast<float>(1.0 / sqrt(n2)) : 0.f;
+}
+
 // lpr lanes per row (power of two >= Dc/16 capped at 64); every lane codes 16 dimensions at a time
 __global__ void __launch_bounds__(kPsThreads)
     ps_encode_kernel(const float* base, uint32_t N, uint32_t D, uint32_t Dc, uint32_t lpr,
-                     uint8_t* codes, float* params)
+                     const float* inv_norm, uint8_t* codes, float* params)
 {
   const uint32_t rows_per_block = kPsThreads / lpr;
   const uint64_t row = static_cast<uint64_t>(block_linear_index()) * rows_per_block +
@@ -118,6 +151,14 @@ __global__ void __launch_bounds__(kPsThreads)
     return;  // the first pass was lossless
   const float s = params[0], inv_s = params[1];
   const float* offs = params + kPsHeader;
+  // cosine: the exactly normalised row (in double) is what the codes are measured against
+  double exact_scale = 1.0;
+  float code_scale = 1.f;
+  if (inv_norm) {
+    const double n2 = ps_row_norm2(base, row, N, D, lpr, g);
+    exact_scale = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+    code_scale = row < N ? inv_norm[row] : 0.f;
+  }
   double err = 0.0;
   if (row < N) {
     const float* x = base + row * D;
@@ -133,9 +174,9 @@ __global__ void __launch_bounds__(kPsThreads)
           if (d < D) {
             const float v = x[d];
             const float o = offs[d];
-            const float c = fminf(fmaxf(rintf((v - o) * inv_s), 0.f), 255.f);
+            const float c = fminf(fmaxf(rintf((v * code_scale - o) * inv_s), 0.f), 255.f);
             w[j] |= static_cast<uint32_t>(c) << (8 * e);
-            const double res = static_cast<double>(v) -
+            const double res = static_cast<double>(v) * exact_scale -
                                (static_cast<double>(o) + static_cast<double>(s) * c);
             err += res * res;
           }
@@ -156,13 +197,13 @@ __global__ void __launch_bounds__(kPsThreads)
 
 // validation probe: evaluates the pre-screen exactly as fetch() does for explicit
 // (query, candidate, criteria) triples.  One wave per query; candidates in rounds of 32.
-template <int LPR, int NCH>
+template <int LPR, int NCH, int MODE>
 __global__ void __launch_bounds__(kWave)
     ps_probe_kernel(const uint8_t* codes, const float* params, uint32_t D, uint32_t Dc,
                     const float* query, uint32_t Nq, const int32_t* cand, uint32_t M,
                     const float* crit, int32_t* reject, float* s_out)
 {
-  using PS = Prescreen<LPR, NCH>;
+  using PS = Prescreen<LPR, NCH, MODE>;
   const uint32_t n = block_linear_index();
   if (n >= Nq)
     return;
@@ -197,13 +238,13 @@ size_t prescreen_param_floats(uint32_t D)
 {
   return kPsHeader + prescreen_code_dim(D);
 }
-size_t prescreen_scratch_floats(uint32_t D)
+size_t prescreen_scratch_floats(uint32_t N, uint32_t D, ggnn_measure measure)
 {
-  return static_cast<size_t>(kPsBlocks) * 2 * D + 4;
+  return static_cast<size_t>(kPsBlocks) * 2 * D + 4 + (measure == GGNN_COSINE ? N : 0);
 }
 
-void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, uint8_t* codes,
-                             float* params, float* scratch, hipStream_t stream)
+void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, ggnn_measure measure,
+                             uint8_t* codes, float* params, float* scratch, hipStream_t stream)
 {
   GGNN_REQUIRE(N >= 1, GGNN_INVALID_ARGUMENT, "empty base");
   GGNN_REQUIRE(D >= 1 && D <= 4096 && D % 4 == 0, GGNN_INVALID_ARGUMENT,
@@ -214,27 +255,33 @@ void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, uint8_t*
   const uint32_t Dc = prescreen_code_dim(D);
   const uint32_t B = std::min(kPsBlocks, N);
   uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + static_cast<size_t>(kPsBlocks) * 2 * D);
-  GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
-  hipLaunchKernelGGL(ps_minmax_kernel, dim3(B), dim3(kPsThreads), 0, stream, base, N, D, B, scratch,
-                     flags);
-  hipLaunchKernelGGL(ps_finalize_kernel, dim3(1), dim3(kPsThreads), 0, stream, scratch, flags, D,
-                     Dc, B, params);
+  float* inv_norm = measure == GGNN_COSINE ? scratch + static_cast<size_t>(kPsBlocks) * 2 * D + 4
+                                           : nullptr;
   uint32_t lpr = 1;
   while (lpr < 64 && lpr * 16 < Dc)
     lpr *= 2;
   const uint32_t rows_per_block = kPsThreads / lpr;
   const dim3 grid = grid_for((static_cast<uint64_t>(N) + rows_per_block - 1) / rows_per_block);
+  GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
+  if (inv_norm)
+    hipLaunchKernelGGL(ps_inv_norm_kernel, grid, dim3(kPsThreads), 0, stream, base, N, D, lpr,
+                       inv_norm);
+  hipLaunchKernelGGL(ps_minmax_kernel, dim3(B), dim3(kPsThreads), 0, stream, base, N, D, B,
+                     inv_norm, scratch, flags);
+  hipLaunchKernelGGL(ps_finalize_kernel, dim3(1), dim3(kPsThreads), 0, stream, scratch, flags, D,
+                     Dc, B, static_cast<int>(measure), params);
   hipLaunchKernelGGL(ps_encode_kernel, grid, dim3(kPsThreads), 0, stream, base, N, D, Dc, lpr,
-                     codes, params);
+                     inv_norm, codes, params);
   hipLaunchKernelGGL(ps_retry_kernel, dim3(1), dim3(1), 0, stream, params);
   hipLaunchKernelGGL(ps_encode_kernel, grid, dim3(kPsThreads), 0, stream, base, N, D, Dc, lpr,
-                     codes, params);
+                     inv_norm, codes, params);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 
 void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
-                            const float* query, uint32_t Nq, const int32_t* cand, uint32_t M,
-                            const float* crit, int32_t* reject, float* s_out, hipStream_t stream)
+                            ggnn_measure measure, const float* query, uint32_t Nq,
+                            const int32_t* cand, uint32_t M, const float* crit, int32_t* reject,
+                            float* s_out, hipStream_t stream)
 {
   if (!Nq || !M)
     return;
@@ -242,9 +289,15 @@ void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t 
                "D must be a multiple of 4 in [4, 4096]");
   const uint32_t Dc = prescreen_code_dim(D);
   const uint32_t chunks = Dc / 16;
-#define GGNN_PROBE(LPR, NCH)                                                                  \
-  hipLaunchKernelGGL((ps_probe_kernel<LPR, NCH>), grid_for(Nq), dim3(kWave), 0, stream, codes, \
-                     params, D, Dc, query, Nq, cand, M, crit, reject, s_out)
+#define GGNN_PROBE(LPR, NCH)                                                                      \
+  do {                                                                                            \
+    if (measure == GGNN_EUCLIDEAN)                                                                \
+      hipLaunchKernelGGL((ps_probe_kernel<LPR, NCH, kL2>), grid_for(Nq), dim3(kWave), 0, stream,  \
+                         codes, params, D, Dc, query, Nq, cand, M, crit, reject, s_out);         \
+    else                                                                                          \
+      hipLaunchKernelGGL((ps_probe_kernel<LPR, NCH, kCos>), grid_for(Nq), dim3(kWave), 0, stream, \
+                         codes, params, D, Dc, query, Nq, cand, M, crit, reject, s_out);         \
+  } while (0)
   // the same layouts launch_query pairs with the float-row layouts
   if (chunks <= 8)
     GGNN_PROBE(8, 1);

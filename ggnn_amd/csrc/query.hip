@@ -19,29 +19,10 @@ struct QueryArgs {
   uint32_t D, Nq, N_base, KBuild, num_start, KQuery, sorted, cache, max_iters;
   uint32_t shards_per_gpu, on_gpu_shard;
   float tau;
-  // optional pre-screen copy of the base (prescreen.hip); float32 + squared L2 only
+  // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
   const uint8_t* ps_codes;
   const float* ps_params;
   uint32_t ps_Dc;
-};
-
-// code-row layout used next to a float-row layout <LPR, NCH> (a code row has a quarter of the
-// 16-byte chunks of the float row)
-template <int LPR, int NCH>
-struct PsFor {
-  using type = Prescreen<8, 1>;
-};
-template <>
-struct PsFor<16, 4> {
-  using type = Prescreen<8, 2>;
-};
-template <>
-struct PsFor<64, 4> {
-  using type = Prescreen<16, 4>;
-};
-template <>
-struct PsFor<64, 16> {
-  using type = Prescreen<64, 4>;
 };
 
 template <class PSC, typename BaseT>
@@ -51,8 +32,16 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
     ps.load(a.ps_codes, a.ps_params, a.ps_Dc, reinterpret_cast<const float*>(qrow), a.D);
 }
 
+// occupancy target of the common instantiations (one register of list per lane, narrow rows,
+// pre-screen): a tuning knob, 1 = leave it to the compiler
+#ifndef GGNN_QUERY_WAVES
+#define GGNN_QUERY_WAVES 7
+#endif
+
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
-__global__ void __launch_bounds__(kWave) query_kernel(const QueryArgs a)
+__global__ void __launch_bounds__(kWave) __attribute__((
+    amdgpu_waves_per_eu((R == 1 && NCH <= 2 && PSC::enabled) ? GGNN_QUERY_WAVES : 1)))
+query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, a.cache);
@@ -243,8 +232,12 @@ static void launch_query_cfg(const QueryArgs& args, bool use_ps, ggnn_measure me
 {
   if constexpr (std::is_same<BaseT, float>::value) {
     if (use_ps) {
-      launch_query_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH>::type>(args, args.sorted,
-                                                                           stream);
+      if (measure == GGNN_EUCLIDEAN)
+        launch_query_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH, kL2>::type>(
+            args, args.sorted, stream);
+      else
+        launch_query_r<BaseT, LPR, NCH, kCos, typename PsFor<LPR, NCH, kCos>::type>(
+            args, args.sorted, stream);
       return;
     }
   }
@@ -282,8 +275,7 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.shards_per_gpu = a.shards_per_gpu;
   args.on_gpu_shard = a.on_gpu_shard;
   args.tau = a.tau_query;
-  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32 &&
-                      a.measure == GGNN_EUCLIDEAN;
+  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
     GGNN_REQUIRE(a.ps_Dc % 16 == 0 && a.ps_Dc >= a.D && a.ps_Dc < a.D + 16,
                  GGNN_INVALID_ARGUMENT, "pre-screen code rows must be D rounded up to 16");

@@ -661,6 +661,8 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
     int rr[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+      if (s > 0 && s0 + s * ROWS >= nsurv)
+        break;  // wave-uniform: no rows left for this and the following steps
       const int r = s0 + s * ROWS + grp;
       const bool valid = r < nsurv;
       rr[s] = valid ? r : -1;
@@ -694,7 +696,7 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact pre-screen of candidates on a compact copy of the rows (float32 rows, squared L2 only).
+// Exact pre-screen of candidates on a compact copy of the rows (float32 rows).
 //
 // ~85 % of the distance evaluations of a traversal end in "d >= criteria(): not pushed"
 // (simple_knn_cache.cuh:283-285) -- for those the value of d is irrelevant.  Every row x is
@@ -721,7 +723,12 @@ struct NoPrescreen {
   static constexpr bool enabled = false;
 };
 
-template <int LPR_, int NCH_>
+// Cosine (MODE = kCos): rows and queries are coded after normalisation to unit length; for unit
+// vectors |1 - cos| = ||q^ - x^||^2 / 2, so the same bound applies to 2 * criteria.  The float
+// evaluation |1 - dot / sqrt(|q|^2 |x|^2)| (distance.cuh:153-158) is within (D+8)u of that in
+// ABSOLUTE terms, covered by adding m to the criteria.  A query of zero norm (distance 1 to
+// everything in the reference) switches the pre-screen off.
+template <int LPR_, int NCH_, int MODE_ = kL2>
 struct Prescreen {
   static constexpr bool enabled = true;
   static constexpr int LPR = LPR_;
@@ -734,6 +741,7 @@ struct Prescreen {
   uint4 qc[NCH];  // codes of the query for this lane's dimensions
   uint32_t qq;    // sum of their squares
   float inv_s, slack, m;
+  bool usable;
 
   GGNN_DEV bool chunk_valid(int c) const
   {
@@ -757,7 +765,38 @@ struct Prescreen {
     g = threadIdx.x % LPR;
     inv_s = params[1];
     const float* offs = params + kPsHeader;
-    float qs = 0.f, eq = 0.f;
+    constexpr float u = 5.9604645e-8f;  // 2^-24
+    m = 4.f * static_cast<float>(Dc + 32) * u;
+
+    // cosine: the norm is needed before coding; the row is read twice (it is in cache) instead
+    // of being held in registers
+    float qs = 0.f;
+    if (MODE_ == kCos) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const uint32_t d0 = static_cast<uint32_t>((c * LPR + g) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (d0 + 4 * j < D) {
+            const float4 v = *reinterpret_cast<const float4*>(qrow + d0 + 4 * j);
+            qs = fmaf(v.x, v.x, qs);
+            qs = fmaf(v.y, v.y, qs);
+            qs = fmaf(v.z, v.z, qs);
+            qs = fmaf(v.w, v.w, qs);
+          }
+        }
+      }
+    }
+    float q_scale = 1.f;
+    usable = true;
+    if (MODE_ == kCos) {
+      const float q_norm = sqrtf(group_sum<LPR>(qs));
+      usable = q_norm > 0.f && q_norm < inf_f();
+      q_scale = usable ? 1.f / q_norm : 0.f;
+      qs = 0.f;
+    }
+
+    float eq = 0.f;
     qq = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -775,7 +814,7 @@ struct Prescreen {
         w[j] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = (qe[e] - oe[e]) * inv_s;
+          const float t = (qe[e] * q_scale - oe[e]) * inv_s;
           const float code = fminf(fmaxf(rintf(t), 0.f), 255.f);
           const float diff = t - code;
           eq = fmaf(diff, diff, eq);
@@ -785,10 +824,13 @@ struct Prescreen {
         qq = __builtin_amdgcn_udot4(w[j], w[j], qq, false);
       }
       qc[c] = make_uint4(w[0], w[1], w[2], w[3]);
+      // one chunk at a time: without this barrier the loads of all chunks are hoisted and the
+      // kernel's register allocation is set by this prologue (184 instead of ~110 VGPRs at D=960)
+      if (NCH > 2)
+        asm volatile("" ::: "memory");
     }
-    constexpr float u = 5.9604645e-8f;  // 2^-24
-    m = 4.f * static_cast<float>(Dc + 32) * u;
-    const float q_norm = sqrtf(group_sum<LPR>(qs));
+    // norm of the vector that was coded (unit length for the cosine measure)
+    const float q_norm = (MODE_ == kCos) ? 1.f : sqrtf(group_sum<LPR>(qs));
     const float e_q = params[0] * sqrtf(group_sum<LPR>(eq)) * (1.f + m);
     slack = e_q + 8.f * u * (q_norm + params[3]) + params[2];
   }
@@ -814,20 +856,44 @@ struct Prescreen {
   // a candidate with group-summed S >= threshold(crit) has a float distance >= crit
   GGNN_DEV float threshold(float crit) const
   {
-    if (!(crit < inf_f()))
+    if (!(crit < inf_f()) || !usable)
       return inf_f();
+    if (MODE_ == kCos)
+      crit = 2.f * (crit + m) * (1.f + m);
     float t = sqrtf(crit) * (1.f + m) + slack;
     t = t * inv_s * (1.f + m);
     return t * t * (1.f + m);
   }
 };
 
+// code-row layout used next to a float-row layout <LPR, NCH> (a code row has a quarter of the
+// 16-byte chunks of the float row)
+template <int LPR, int NCH, int MODE>
+struct PsFor {
+  using type = Prescreen<8, 1, MODE>;
+};
+template <int MODE>
+struct PsFor<16, 4, MODE> {
+  using type = Prescreen<8, 2, MODE>;
+};
+template <int MODE>
+struct PsFor<64, 4, MODE> {
+  using type = Prescreen<16, 4, MODE>;
+};
+template <int MODE>
+struct PsFor<64, 16, MODE> {
+  using type = Prescreen<64, 4, MODE>;
+};
+
 // Drops the candidates of lds.ckeys[0,nsurv) whose lower bound reaches the criteria; the others
-// are compacted in place (order kept).  Returns their number.
+// are compacted in place (order kept).  Returns their number.  translation: optional map from
+// candidate keys to base rows (upper graph layers).
 template <class PS>
-GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s_thr)
+GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s_thr,
+                            const int32_t* translation)
 {
-  constexpr int STEPS = StepsOf<PS::LPR, PS::NCH>::value;
+  // 3 x 8 rows cover the usual KBuild = 24 neighbours of a graph row in one round
+  constexpr int STEPS = (PS::NCH == 1) ? 3 : StepsOf<PS::LPR, PS::NCH>::value;
   constexpr int ROWS = PS::ROWS;
   const int lane = threadIdx.x;
   const int grp = lane / PS::LPR;
@@ -840,7 +906,10 @@ GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s
       const int r = s0 + s * ROWS + grp;
       const bool valid = r < nsurv;
       kk[s] = valid ? lds.ckeys[r] : kEmptyKey;
-      const uint8_t* row = ps.row_ptr(valid ? kk[s] : 0);
+      int m = valid ? kk[s] : 0;
+      if (valid && translation)
+        m = translation[m];
+      const uint8_t* row = ps.row_ptr(m);
 #pragma unroll
       for (int c = 0; c < PS::NCH; ++c) {
         v[s][c] = make_uint4(0u, 0u, 0u, 0u);
@@ -887,7 +956,7 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
   if constexpr (PS::enabled) {
     const float s_thr = ps.threshold(sl.criteria());
     if (s_thr < inf_f()) {
-      neval = prescreen_pass(ps, lds, nsurv, s_thr);
+      neval = prescreen_pass(ps, lds, nsurv, s_thr, translation);
       rows.y += nsurv;
       if (neval == 0)
         return nsurv;

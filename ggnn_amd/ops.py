@@ -65,26 +65,27 @@ def query_sizing(D, k_query, max_iterations):
     return cache.value, sorted_.value
 
 
-def prescreen_sizes(D):
+def prescreen_sizes(N, D, measure=EUCLIDEAN):
     import ctypes as C
     dc, pf, sf = C.c_uint32(), C.c_size_t(), C.c_size_t()
-    check(lib().ggnn_prescreen_sizes(D, C.byref(dc), C.byref(pf), C.byref(sf)))
+    check(lib().ggnn_prescreen_sizes(N, D, measure, C.byref(dc), C.byref(pf), C.byref(sf)))
     return dc.value, pf.value, sf.value
 
 
-def prescreen_encode(base):
-    """8-bit pre-screen copy of a float32 base: (codes [N, code_dim] uint8, params float32)."""
+def prescreen_encode(base, measure=EUCLIDEAN):
+    """8-bit pre-screen copy of a float32 base for `measure`:
+    (codes [N, code_dim] uint8, params float32)."""
     _need(base, torch.float32, "base")
-    dc, pf, sf = prescreen_sizes(base.shape[1])
+    dc, pf, sf = prescreen_sizes(base.shape[0], base.shape[1], measure)
     codes = torch.empty((base.shape[0], dc), dtype=torch.uint8, device=base.device)
     params = torch.empty(pf, dtype=torch.float32, device=base.device)
     scratch = torch.empty(sf, dtype=torch.float32, device=base.device)
-    check(lib().ggnn_op_prescreen_encode(_ptr(base), base.shape[0], base.shape[1], _ptr(codes),
-                                         _ptr(params), _ptr(scratch), _stream()))
+    check(lib().ggnn_op_prescreen_encode(_ptr(base), base.shape[0], base.shape[1], measure,
+                                         _ptr(codes), _ptr(params), _ptr(scratch), _stream()))
     return codes, params
 
 
-def prescreen_probe(codes, params, query, cand, crit):
+def prescreen_probe(codes, params, query, cand, crit, measure=EUCLIDEAN):
     """reject [Nq, M] int32 and coded squared distances [Nq, M] for explicit triples."""
     _need(codes, torch.uint8, "codes"), _need(params, torch.float32, "params")
     _need(query, torch.float32, "query"), _need(cand, torch.int32, "cand")
@@ -92,16 +93,16 @@ def prescreen_probe(codes, params, query, cand, crit):
     Nq, M = cand.shape
     reject = torch.empty((Nq, M), dtype=torch.int32, device=codes.device)
     s_out = torch.empty((Nq, M), dtype=torch.float32, device=codes.device)
-    check(lib().ggnn_op_prescreen_probe(_ptr(codes), _ptr(params), query.shape[1], _ptr(query), Nq,
-                                        _ptr(cand), M, _ptr(crit), _ptr(reject), _ptr(s_out),
-                                        _stream()))
+    check(lib().ggnn_op_prescreen_probe(_ptr(codes), _ptr(params), query.shape[1], measure,
+                                        _ptr(query), Nq, _ptr(cand), M, _ptr(crit), _ptr(reject),
+                                        _ptr(s_out), _stream()))
     return reject, s_out
 
 
 def query(base, query, graph0, start, nn1_stats, k_query, tau_query, max_iterations=400,
           measure=EUCLIDEAN, shards_per_gpu=1, on_gpu_shard=0, out=None, counters=False,
           prescreen=None, rows_read=None):
-    """prescreen: optional (codes, params) of prescreen_encode(base) (float32, Euclidean);
+    """prescreen: optional (codes, params) of prescreen_encode(base, measure) (float32);
     rows_read: optional int32 [Nq, 2] tensor receiving the float / code rows read per query."""
     _need(base, name="base"), _need(query, base.dtype, "query")
     _need(graph0, torch.int32, "graph0"), _need(start, torch.int32, "start")
@@ -121,12 +122,11 @@ def query(base, query, graph0, start, nn1_stats, k_query, tau_query, max_iterati
         codes, params = prescreen
         _need(base, torch.float32, "base"), _need(codes, torch.uint8, "codes")
         _need(params, torch.float32, "params")
-        if measure != EUCLIDEAN:
-            raise ValueError("the pre-screen is defined for the Euclidean measure only")
         check(lib().ggnn_op_query_prescreened(
             _ptr(base), base.shape[0], base.shape[1], _ptr(codes), _ptr(params), _ptr(query), Nq,
             _ptr(graph0), graph0.shape[1], _ptr(start), start.numel(), _ptr(nn1_stats), k_query,
-            tau_query, max_iterations, shards_per_gpu, on_gpu_shard, _ptr(ids), _ptr(dists),
+            tau_query, max_iterations, measure, shards_per_gpu, on_gpu_shard, _ptr(ids),
+            _ptr(dists),
             _ptr(nd), _ptr(npop), _ptr(rows_read), _stream()))
     else:
         check(lib().ggnn_op_query(_ptr(base), _dtype_code(base), base.shape[0], base.shape[1],
@@ -161,17 +161,26 @@ def top(base, KBuild, translation_layer, N_layer, S, S_offset, layer, measure=EU
 
 
 def merge(base, cfg, graph_all, translation_all, selection_all, nn1_stats, tau_build, layer_top,
-          layer_btm, measure=EUCLIDEAN, counters=False):
+          layer_btm, measure=EUCLIDEAN, counters=False, prescreen=None):
     _need(base, name="base"), _need(graph_all, torch.int32, "graph_all")
     _need(translation_all, torch.int32), _need(selection_all, torch.int32)
     Nb = cfg.Ns[layer_btm]
     gb = torch.empty((Nb, cfg.KBuild), dtype=torch.int32, device=base.device)
     nn1 = torch.zeros(Nb, dtype=torch.float32, device=base.device)
     nd = torch.zeros(Nb, dtype=torch.int32, device=base.device) if counters else None
-    check(lib().ggnn_op_merge(_ptr(base), _dtype_code(base), measure, _cfg(cfg), _ptr(graph_all),
-                              _ptr(translation_all), _ptr(selection_all), _ptr(nn1_stats),
-                              tau_build, layer_top, layer_btm, _ptr(gb), _ptr(nn1), _ptr(nd),
-                              _stream()))
+    if prescreen is not None:
+        codes, params = prescreen
+        _need(base, torch.float32, "base"), _need(codes, torch.uint8, "codes")
+        _need(params, torch.float32, "params")
+        check(lib().ggnn_op_merge_prescreened(
+            _ptr(base), _ptr(codes), _ptr(params), measure, _cfg(cfg), _ptr(graph_all),
+            _ptr(translation_all), _ptr(selection_all), _ptr(nn1_stats), tau_build, layer_top,
+            layer_btm, _ptr(gb), _ptr(nn1), _ptr(nd), _stream()))
+    else:
+        check(lib().ggnn_op_merge(_ptr(base), _dtype_code(base), measure, _cfg(cfg),
+                                  _ptr(graph_all), _ptr(translation_all), _ptr(selection_all),
+                                  _ptr(nn1_stats), tau_build, layer_top, layer_btm, _ptr(gb),
+                                  _ptr(nn1), _ptr(nd), _stream()))
     if counters:
         return gb, nn1, nd
     return gb, nn1

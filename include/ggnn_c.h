@@ -132,7 +132,7 @@ ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
 /* rows the last ggnn_query read for those evaluations (needs collect_counters): float rows
  * (4*D bytes each) and, with the pre-screen, 8-bit code rows (D rounded up to 16 bytes each). */
 ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows);
-/* Exact pre-screen of the float32 / Euclidean query kernel (no reference counterpart; results
+/* Exact pre-screen of the float32 query and merge kernels (no reference counterpart; results
  * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
  * environment variable GGNN_PRESCREEN=0 turns the default off. */
 ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable);
@@ -164,36 +164,39 @@ ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, u
 
 /* Pre-screen copy of a float32 base (no reference counterpart; an exact pruning aid of
  * query_layer.cu:69-77 / simple_knn_cache.cuh:268-286): every row is stored a second time as
- * 8-bit codes c with x^_d = o_d + s*c_d plus a bound e_max >= max_rows ||x - x^||.  During a
- * Euclidean float32 query a candidate whose lower bound (||q - x^|| - e_max)^2 already reaches
- * the criteria is dropped without reading its float row -- exactly the candidates the reference
- * evaluates and then discards -- so ids, distances and counters do not change.
+ * 8-bit codes c with x^_d = o_d + s*c_d plus a bound e_max >= max_rows ||x - x^|| (cosine: of the
+ * row normalised to unit length).  During a float32 query or merge a candidate whose lower
+ * bound (||q^ - x^|| - e_q - e_max)^2 already reaches the criteria is dropped without reading
+ * its float row -- exactly the candidates the reference evaluates and then discards -- so ids,
+ * distances and counters do not change.  The copy is specific to the measure it was made for.
  * code_dim = D rounded up to 16; codes [N_base x code_dim] bytes; params [param_floats] floats
  * ([0] s, [1] 1/s, [2] e_max, [3] ||o||, [4] usable (0 when the data holds non-finite values),
- * [5..7] internal, [8..] o_d); scratch [scratch_floats] floats.  D must be a multiple of 4. */
-ggnn_status ggnn_prescreen_sizes(uint32_t D, uint32_t* code_dim, size_t* param_floats,
-                                 size_t* scratch_floats);
+ * [5..6] internal, [7] measure, [8..] o_d); scratch [scratch_floats] floats.  D must be a
+ * multiple of 4. */
+ggnn_status ggnn_prescreen_sizes(uint32_t N_base, uint32_t D, ggnn_measure measure,
+                                 uint32_t* code_dim, size_t* param_floats, size_t* scratch_floats);
 ggnn_status ggnn_op_prescreen_encode(const float* base, uint32_t N_base, uint32_t D,
-                                     uint8_t* codes, float* params, float* scratch, void* stream);
+                                     ggnn_measure measure, uint8_t* codes, float* params,
+                                     float* scratch, void* stream);
 /* Validation probe: for query n and candidate cand[n*M+j], reject[n*M+j] = 1 iff the pre-screen
  * would drop the candidate at criteria crit[n*M+j]; s_out (optional) receives the coded squared
  * distance in code units.  A correct bound never rejects at a criteria above the float
  * distance of the pair. */
 ggnn_status ggnn_op_prescreen_probe(const uint8_t* codes, const float* params, uint32_t D,
-                                    const float* query, uint32_t Nq, const int32_t* cand,
-                                    uint32_t M, const float* crit, int32_t* reject, float* s_out,
-                                    void* stream);
-/* ggnn_op_query for float32 / Euclidean with the pre-screen copy (params[4] must be 1).
+                                    ggnn_measure measure, const float* query, uint32_t Nq,
+                                    const int32_t* cand, uint32_t M, const float* crit,
+                                    int32_t* reject, float* s_out, void* stream);
+/* ggnn_op_query for float32 with the pre-screen copy made for `measure` (params[4] must be 1).
  * n_rows: optional [Nq x 2], float rows and code rows read per query. */
 ggnn_status ggnn_op_query_prescreened(const float* base, uint32_t N_base, uint32_t D,
                                       const uint8_t* codes, const float* params,
                                       const float* query, uint32_t Nq, const int32_t* graph0,
                                       uint32_t KBuild, const int32_t* start, uint32_t num_start,
                                       const float* nn1_stats, uint32_t k_query, float tau_query,
-                                      uint32_t max_iterations, uint32_t shards_per_gpu,
-                                      uint32_t on_gpu_shard, int32_t* ids, float* dists,
-                                      uint32_t* n_dist, uint32_t* n_pop, uint32_t* n_rows,
-                                      void* stream);
+                                      uint32_t max_iterations, ggnn_measure measure,
+                                      uint32_t shards_per_gpu, uint32_t on_gpu_shard, int32_t* ids,
+                                      float* dists, uint32_t* n_dist, uint32_t* n_pop,
+                                      uint32_t* n_rows, void* stream);
 
 /* QueryKernels::bruteForceQuery  query_kernels.cu:188-264 -> bf_query_layer.cu:39-65 */
 ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
@@ -216,6 +219,16 @@ ggnn_status ggnn_op_merge(const void* base, ggnn_dtype dtype, ggnn_measure measu
                           const float* nn1_stats, float tau_build, uint32_t layer_top,
                           uint32_t layer_btm, int32_t* graph_buffer, float* nn1_dist_buffer,
                           uint32_t* n_dist, void* stream);
+/* ggnn_op_merge for float32 with the pre-screen copy of the base made for `measure`
+ * (ggnn_op_prescreen_encode, params[4] must be 1); same outputs. */
+ggnn_status ggnn_op_merge_prescreened(const float* base, const uint8_t* codes, const float* params,
+                                      ggnn_measure measure, const ggnn_graph_config* cfg,
+                                      const int32_t* graph_all,
+                                      const int32_t* translation_all,
+                                      const int32_t* selection_all, const float* nn1_stats,
+                                      float tau_build, uint32_t layer_top, uint32_t layer_btm,
+                                      int32_t* graph_buffer, float* nn1_dist_buffer,
+                                      uint32_t* n_dist, void* stream);
 
 /* select  graph_construction.cu:163-187 -> wrs_select_layer.cu:41-102.  rng [Ns[layer]] uniform
  * (0,1] numbers (the reference draws them with cuRAND XORWOW; injected here). */

@@ -33,6 +33,7 @@ double g_margin_min = std::numeric_limits<double>::infinity();
 // (identical results on integer-valued data, where every summation order is exact)
 int g_fast_distance = 0;
 std::atomic<uint64_t> g_accept_total{0};
+std::atomic<uint64_t> g_eval_total{0};
 
 // include/ggnn/base/def.h:37-56
 inline uint32_t bit_ceil_u32(uint32_t v)
@@ -591,6 +592,11 @@ void orc_set_fast_distance(int enable)
   g_fast_distance = enable;
 }
 
+uint64_t orc_eval_total(int reset)
+{
+  return reset ? g_eval_total.exchange(0) : g_eval_total.load();
+}
+
 uint64_t orc_accept_total(int reset)
 {
   return reset ? g_accept_total.exchange(0) : g_accept_total.load();
@@ -793,6 +799,7 @@ void orc_query(const void* base, uint32_t N, uint32_t D, int dtype, const void* 
     if (n_pop)
       n_pop[n] = pops;
     g_accept_total.fetch_add(dc.n_accepted);
+    g_eval_total.fetch_add(dc.n_calls);
   });
 }
 
@@ -970,6 +977,8 @@ void orc_merge(const void* base, int dtype, int measure, const OrcGraphConfig* c
     }
     if (n_dist)
       n_dist[n] = (uint32_t)dc.n_calls;
+    g_accept_total.fetch_add(dc.n_accepted);
+    g_eval_total.fetch_add(dc.n_calls);
   });
 }
 

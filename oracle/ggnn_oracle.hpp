@@ -144,6 +144,8 @@ void orc_wave_model_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, float
 void orc_set_fast_distance(int enable);
 // statistics: number of distance evaluations accepted (d < criteria) by orc_query since reset
 uint64_t orc_accept_total(int reset);
+// statistics: number of distance evaluations of orc_query / orc_merge since reset
+uint64_t orc_eval_total(int reset);
 void orc_margin_reset();
 double orc_margin_min();
 

@@ -315,3 +315,26 @@ def test_prescreen_toggle_gives_identical_results():
         assert np.array_equal(out[0][0], o[0])
         assert np.array_equal(out[0][1], o[1])
         assert out[0][2] == o[2]
+
+
+def test_prescreen_follows_the_measure():
+    # one handle, Euclidean build then cosine and Euclidean queries: the pre-screen copy is
+    # re-coded for the measure in use and results equal the plain kernels
+    import ggnn_amd as ggnn
+    rng = np.random.default_rng(6)
+    centres = rng.normal(size=(16, 128)) * 3
+    base = (centres[rng.integers(0, 16, 5000)] + rng.normal(size=(5000, 128))).astype(np.float32)
+    q = (centres[rng.integers(0, 16, 200)] + rng.normal(size=(200, 128))).astype(np.float32)
+    g = ggnn.GGNN()
+    g.set_base(base)
+    g.build(24, 0.5, 1)
+    res = {}
+    for measure in (ggnn.DistanceMeasure.Cosine, ggnn.DistanceMeasure.Euclidean,
+                    ggnn.DistanceMeasure.Cosine):
+        for enable in (True, False):
+            g.set_prescreen(enable)
+            ids, d = g.query(q, 10, 0.7, 200, measure)
+            res.setdefault((measure, enable), (np.asarray(ids), np.asarray(d)))
+            assert np.array_equal(res[(measure, enable)][0], np.asarray(ids))
+        assert np.array_equal(res[(measure, True)][0], res[(measure, False)][0])
+        assert np.array_equal(res[(measure, True)][1], res[(measure, False)][1])

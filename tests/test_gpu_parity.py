@@ -591,7 +591,7 @@ def _clustered(N, D, seed, offset=0.0, scale=1.0):
 
 def test_prescreen_sizes_and_lossless_integers(ops):
     base = dev(make_int_data(3000, 128, 5))
-    assert ops.prescreen_sizes(128)[0] == 128 and ops.prescreen_sizes(100)[0] == 112
+    assert ops.prescreen_sizes(3000, 128)[0] == 128 and ops.prescreen_sizes(3000, 100)[0] == 112
     codes, params = ops.prescreen_encode(base)
     p = params.cpu().numpy()
     assert p[0] == 1.0 and p[1] == 1.0 and p[2] == 0.0 and p[4] == 1.0
@@ -678,3 +678,90 @@ def test_query_prescreened_wide_rows(ops, orc, D):
     fast = ops.query(b, qq, g0, st, ss, 10, 0.7, 200, counters=True, prescreen=ps)
     for x, y in zip(plain, fast):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("top,btm", [(1, 0), (3, 0), (3, 2), (2, 1)])
+def test_merge_prescreened_exact(ops, orc, small_graph, top, btm):
+    g = small_graph
+    c = g["cfg"]
+    b = dev(g["base"])
+    ps = ops.prescreen_encode(b)
+    gb, nn1, nd = ops.merge(b, c, dev(g["graph"]), dev(g["tr"]), dev(g["sel"]), dev(g["stats"]),
+                            0.5, top, btm, counters=True, prescreen=ps)
+    o_gb, o_nn1, o_nd = orc.merge(g["base"], c, g["graph"], g["tr"], g["sel"], g["stats"], 0.5,
+                                  top, btm, counters=True)
+    assert np.array_equal(gb.cpu().numpy(), o_gb)
+    assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+    if btm == 0:
+        assert np.array_equal(nn1.cpu().numpy(), o_nn1)
+
+
+@pytest.mark.parametrize("maker,D", [(_clustered, 128), (_quarter_data, 128), (_clustered, 200),
+                                     (make_uni_data, 64)])
+def test_merge_prescreened_equals_plain_merge(ops, orc, maker, D):
+    N, K = 2500, 24
+    base = maker(N, D, 101)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, rng=orc.make_rng(N, 9))
+    b, ga, ta, sa, ss = dev(base), dev(graph), dev(tr), dev(sel), dev(stats)
+    ps = ops.prescreen_encode(b)
+    for top, btm in ((3, 0), (2, 0), (3, 1)):
+        plain = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, top, btm, counters=True)
+        fast = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, top, btm, counters=True, prescreen=ps)
+        for x, y in zip(plain, fast):
+            assert torch.equal(x, y)
+
+
+# --- cosine -----------------------------------------------------------------------------------
+def _cos_dist64(q, x):
+    qn = np.sqrt((q.astype(np.float64) ** 2).sum(-1))
+    xn = np.sqrt((x.astype(np.float64) ** 2).sum(-1))
+    dot = (q.astype(np.float64) * x.astype(np.float64)).sum(-1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = np.abs(1.0 - dot / (qn * xn))
+    return np.where(qn * xn > 0, d, 1.0)
+
+
+@pytest.mark.parametrize("maker,D", [(_clustered, 128), (make_int_data, 128), (_clustered, 960),
+                                     (make_uni_data, 64)])
+def test_prescreen_cosine_bound_never_exceeds_the_float_distance(ops, maker, D):
+    N, Nq, M = 4000, 48, 96
+    base, q = maker(N, D, 71), maker(Nq, D, 72)
+    base[5] = 0.0  # a zero row has distance 1 to everything
+    codes, params = ops.prescreen_encode(dev(base), 1)
+    p = params.cpu().numpy()
+    assert p[4] == 1.0 and p[7] == 1.0
+    rng = np.random.default_rng(73)
+    cand = rng.integers(0, N, (Nq, M)).astype(np.int32)
+    cand[:, 0] = 5
+    d = _cos_dist64(q[:, None, :], base[cand])
+    # a float32 evaluation lies within (D+8) * 2^-24 (absolute) of the exact value
+    below = (d - 3.0 * (D + 8) * 2.0 ** -24).astype(np.float32)
+    rej, _ = ops.prescreen_probe(codes, params, dev(q), dev(cand), dev(below), 1)
+    assert int(rej.sum()) == 0
+    rej, _ = ops.prescreen_probe(codes, params, dev(q), dev(cand), dev((d * 0.5).astype(np.float32)),
+                                 1)
+    assert rej.float().mean().item() > 0.9
+
+
+@pytest.mark.parametrize("maker,D", [(_clustered, 128), (make_int_data, 128), (_clustered, 320)])
+def test_query_and_merge_prescreened_cosine_equal_plain(ops, orc, maker, D):
+    N, K = 2500, 24
+    base, q = maker(N, D, 111), maker(150, D, 112)
+    base[7] = 0.0
+    q[3] = 0.0  # zero-norm query: the reference returns distance 1 for every candidate
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, measure=1, rng=orc.make_rng(N, 10))
+    start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
+    b, qq, ga, ta, sa, ss = dev(base), dev(q), dev(graph), dev(tr), dev(sel), dev(stats)
+    g0, st = dev(graph[:N]), dev(start)
+    ps = ops.prescreen_encode(b, 1)
+    assert ps[1].cpu().numpy()[4] == 1.0
+    for kq, tau, iters in ((10, 0.6, 200), (100, 0.5, 400)):
+        plain = ops.query(b, qq, g0, st, ss, kq, tau, iters, 1, counters=True)
+        fast = ops.query(b, qq, g0, st, ss, kq, tau, iters, 1, counters=True, prescreen=ps)
+        for x, y in zip(plain, fast):
+            assert torch.equal(x, y)
+    for top, btm in ((3, 0), (2, 1)):
+        plain = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, top, btm, 1, counters=True)
+        fast = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, top, btm, 1, counters=True, prescreen=ps)
+        for x, y in zip(plain, fast):
+            assert torch.equal(x, y)
