@@ -93,8 +93,11 @@ def test_bf_query_uint8(ops, orc):
 # ---------------------------------------------------------------------------------------------
 # query
 # ---------------------------------------------------------------------------------------------
+# the last two cases pop more keys than the visited ring holds (cache 256, ring 192): entries are
+# overwritten in ring order and leave the visited hash set again
 @pytest.mark.parametrize("K,tau,iters", [(10, 0.34, 200), (10, 0.64, 400), (1, 0.5, 100),
-                                         (40, 0.6, 400), (100, 0.6, 512), (10, 0.9, 1000)])
+                                         (40, 0.6, 400), (100, 0.6, 512), (10, 0.9, 1000),
+                                         (10, 2.5, 250), (24, 3.0, 255)])
 def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
     g = small_graph
     q = make_int_data(128, g["D"], 4321)
@@ -107,6 +110,8 @@ def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
     assert np.array_equal(d.cpu().numpy(), o_d)
     assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
     assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+    if iters in (250, 255):
+        assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the visited ring"
 
 
 def test_query_shard_offsets(ops, orc, small_graph):
