@@ -76,9 +76,13 @@ struct TileStage;
 template <>
 struct TileStage<float> {
   float4 r[4];
+  float bn;  // threads 0..31: squared norm of tile row threadIdx.x (pad value past the end)
   GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
-                     uint32_t CW)
+                     uint32_t CW, const float* bnorm, float bn_pad)
   {
+    bn = bn_pad;
+    if (threadIdx.x < (uint32_t)kBfTileRows && row0 + threadIdx.x < end)
+      bn = bnorm[row0 + threadIdx.x];
     const uint32_t cpr = CW / 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -91,6 +95,8 @@ struct TileStage<float> {
   }
   GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
   {
+    if (threadIdx.x < (uint32_t)kBfTileRows)
+      tile[threadIdx.x * DP + CW] = bn;  // spare column behind the chunk (DP >= CW + 4)
     const uint32_t cpr = CW / 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -106,9 +112,13 @@ struct TileStage<float> {
 template <>
 struct TileStage<uint8_t> {
   uint4 r;
+  float bn;
   GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
-                     uint32_t CW)
+                     uint32_t CW, const float* bnorm, float bn_pad)
   {
+    bn = bn_pad;
+    if (threadIdx.x < (uint32_t)kBfTileRows && row0 + threadIdx.x < end)
+      bn = bnorm[row0 + threadIdx.x];
     const uint32_t cpr = CW / 16;
     const uint32_t row = threadIdx.x / cpr, col = col0 + 16 * (threadIdx.x % cpr);
     r = make_uint4(0u, 0u, 0u, 0u);
@@ -117,6 +127,8 @@ struct TileStage<uint8_t> {
   }
   GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
   {
+    if (threadIdx.x < (uint32_t)kBfTileRows)
+      tile[threadIdx.x * DP + CW] = bn;
     const uint32_t cpr = CW / 16;
     const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
     if (row < (uint32_t)kBfTileRows) {
@@ -163,14 +175,85 @@ GGNN_DEV void load_query_chunk(float (&aq)[64], const uint8_t* qrow, bool qvalid
   }
 }
 
+// Rare path of the epilogue: stable insertion of the tile's distances that beat a list's worst
+// entry, candidates in ascending lane order (= ascending base index within each query row).
+// dd[r] / thr[r]: distance and threshold of register row r (query row (r&3) + 8*(r>>2) + 4*h).
+GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t row0, float* wave_d,
+                             int* wave_id, uint32_t KP, int h)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    unsigned long long m = __ballot(dd[r] < thr[r]);
+    while (m) {
+      const int l = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const float dl = rdlanef(dd[r], l);
+      const int hh = l >> 5;
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float* Ld = wave_d + qi * KP;
+      int* Li = wave_id + qi * KP;
+      if (!(dl < Ld[KP - 1]))
+        continue;
+      const int id = static_cast<int>(row0 + (l & 31));
+      // lane owns entries k = c*64 + lane (c < 4); stable insert: everything <= dl stays, the
+      // first larger entry becomes dl, the rest shift by one
+      float cur[4], prev[4];
+      int previ[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = c * kWave + lane;
+        const bool own = k < (int)KP;
+        cur[c] = own ? Ld[k] : inf_f();
+        prev[c] = (own && k > 0) ? Ld[k - 1] : -inf_f();
+        previ[c] = (own && k > 0) ? Li[k - 1] : kEmptyKey;
+      }
+      // one wave: the loads above are issued for all lanes before the stores below (LDS
+      // operations of a wave execute in order); only the compiler must not reorder them
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = c * kWave + lane;
+        if (k < (int)KP && dl < cur[c]) {
+          const bool first = !(dl < prev[c]);  // previous entry stays: insert here
+          Ld[k] = first ? dl : prev[c];
+          Li[k] = first ? id : previ[c];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // the list's new worst entry is the threshold of register row r in half-wave hh
+      const float worst = Ld[KP - 1];
+      if (h == hh)
+        thr[r] = worst;
+    }
+  }
+}
+
+// distance of one accumulator entry (expanded form; invalid base rows give +inf)
+template <int MODE>
+GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
+{
+  if (MODE == kL2)
+    return fmaf(-2.0f, dot, qn + bn);  // bn = +inf for rows past the end
+  const float norm_sqr = qn * bn;
+  const float d = (norm_sqr > 0.0f) ? fabsf(1.0f - dot / sqrtf(norm_sqr)) : 1.0f;
+  return jvalid ? d : inf_f();
+}
+
 // T = base tiles per group whose accumulators stay in registers while the K chunks stream by
-// (T = 1 for D <= 128: a single chunk, the query tile is loaded once per workgroup)
-template <typename BaseT, int MODE, int T>
+// (T = 1 for D <= 128: a single chunk, the query tile is loaded once per workgroup).
+// NU (T = 1 only): float4 steps per half row, Dh = 4*NU -- a compile-time trip count keeps the
+// MFMA chain of a tile in ONE basic block so that the LDS reads of the B operand are scheduled
+// ahead of the MFMAs that consume them.
+template <typename BaseT, int MODE, int T, int NU>
 __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
-  float* tile[2] = {lds_f, lds_f + kBfTileRows * a.DP};
-  float* list_d = lds_f + 2 * kBfTileRows * a.DP;
+  // the two tile buffers are addressed as lds_f + offset (never through a pointer array: a select
+  // between pointers decays to generic addressing, i.e. flat loads that wait on vmcnt(0) and with
+  // it on the prefetch of the next tile)
+  const uint32_t tile_floats = kBfTileRows * a.DP;
+  float* list_d = lds_f + 2 * tile_floats;
   int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -202,14 +285,88 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
     qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
   }
 
+  // thr[r]: worst entry of the candidate list of query row i(r); nothing beats -inf (padding)
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    thr[r] = qi < a.Nq ? inf_f() : -inf_f();
+  }
+
+  // squared norm standing in for rows past the end of the slice: +inf distance for L2
+  const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
   TileStage<BaseT> stage;
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
-    stage.load(base, a.D, begin, end, 0, CW);
-    stage.store(tile[0], a.DP, CW);
+    stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
+    stage.store(lds_f, a.DP, CW);
   }
   __syncthreads();
 
+  if constexpr (T == 1) {
+    // One chunk per row (D <= 128): the epilogue of tile t-1 is interleaved with the MFMA chain
+    // of tile t -- its 16 x (add, fma, compare) are independent of the running accumulator, so
+    // the matrix pipe does not drain between tiles.  Before the first tile the "previous"
+    // accumulator is a dummy whose distances are +inf.
+    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
+    f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bn_prev = bn_pad;
+    bool jvalid_prev = false;
+    uint32_t row0_prev = begin;
+    float* wave_d = list_d + wave * 32 * KP;
+    int* wave_id = list_id + wave * 32 * KP;
+    // Everything loaded so far (query chunk, query norms) must have arrived BEFORE the loop: a
+    // first use inside the loop makes the compiler wait for vmcnt(0) in every iteration, which
+    // also waits for the prefetch of the next tile issued just before (s_waitcnt vmcnt(0)).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (uint32_t tt = 0; tt < ntiles; ++tt) {
+      const uint32_t row0 = begin + tt * kBfTileRows;
+      const bool jvalid = row0 + j < end;
+      // norm of this lane's tile row, staged next to the tile (an LDS read: a global load here
+      // would make the compiler wait for vmcnt(0), i.e. for the prefetch of the next tile)
+      const float bn = lds_f[(tt & 1) * tile_floats + j * a.DP + CW];
+      const bool has_next = tt + 1 < ntiles;
+      if (has_next)
+        stage.load(base, a.D, row0 + kBfTileRows, end, 0, CW, a.bnorm, bn_pad);
+      f32x16 acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* bt = lds_f + (tt & 1) * tile_floats + j * a.DP + h * a.Dh;
+      float dd[16];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (u < NU) {
+          const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc, 0, 0, 0);
+        }
+        dd[u] = bf_expand<MODE>(acc_prev[u], qn[u], bn_prev, jvalid_prev);
+        any |= __ballot(dd[u] < thr[u]);
+      }
+      if (any)
+        bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+      if (has_next)
+        stage.store(lds_f + ((tt + 1) & 1) * tile_floats, a.DP, CW);
+      __syncthreads();
+      acc_prev = acc;
+      bn_prev = bn;
+      jvalid_prev = jvalid;
+      row0_prev = row0;
+    }
+    if (ntiles) {
+      float dd[16];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dd[r] = bf_expand<MODE>(acc_prev[r], qn[r], bn_prev, jvalid_prev);
+        any |= __ballot(dd[r] < thr[r]);
+      }
+      if (any)
+        bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+    }
+  }
+  else {
   uint32_t p = 0;  // (tile, chunk) pairs processed: buffer p&1 holds the current pair
   for (uint32_t g0 = 0; g0 < ntiles; g0 += T) {
     f32x16 acc[T];
@@ -241,10 +398,11 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
             has_next = false;
         }
         if (has_next)
-          stage.load(base, a.D, begin + n_tile * kBfTileRows, end, n_chunk * CW, CW);
+          stage.load(base, a.D, begin + n_tile * kBfTileRows, end, n_chunk * CW, CW, a.bnorm,
+                     bn_pad);
 
         // S += Q_chunk x B_chunk^T for this wave's 32 queries against the 32 tile rows
-        const float* bt = tile[p & 1] + j * a.DP + h * a.Dh;
+        const float* bt = lds_f + (p & 1) * tile_floats + j * a.DP + h * a.Dh;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           if (static_cast<uint32_t>(4 * u) < a.Dh) {
@@ -256,13 +414,15 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           }
         }
         if (has_next)
-          stage.store(tile[(p + 1) & 1], a.DP, CW);
+          stage.store(lds_f + ((p + 1) & 1) * tile_floats, a.DP, CW);
         __syncthreads();
         ++p;
       }
     }
 
-    // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows
+    // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows.  The
+    // thresholds (worst list entry of each of the lane's query rows) live in registers and change
+    // only after an insertion, so the common case is 16 x (add, fma, compare) and one branch.
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const uint32_t tt = g0 + t;
@@ -270,64 +430,21 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
         break;
       const uint32_t row0 = begin + tt * kBfTileRows;
       const bool jvalid = row0 + j < end;
-      const float bn = jvalid ? a.bnorm[row0 + j] : 0.f;
+      // rows past the end: +inf norm -> +inf distance (L2); handled explicitly for cosine
+      const float bn = jvalid ? a.bnorm[row0 + j] : (MODE == kL2 ? inf_f() : 0.f);
+      float dd[16];
+      unsigned long long any = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float d;
-        if (MODE == kL2) {
-          d = fmaf(-2.0f, acc[t][r], qn[r] + bn);
-        }
-        else {
-          const float norm_sqr = qn[r] * bn;
-          d = (norm_sqr > 0.0f) ? fabsf(1.0f - acc[t][r] / sqrtf(norm_sqr)) : 1.0f;
-        }
-        if (!jvalid)
-          d = inf_f();
-        // threshold = current worst list entry of the query this register row belongs to
-        const int qi_own = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float thr = list_d[(wave * 32 + qi_own) * KP + KP - 1];
-        unsigned long long m = __ballot(d < thr);
-        // rare path: stable insertion, candidates in ascending lane order (= ascending base
-        // index within each query row)
-        while (m) {
-          const int l = __ffsll(static_cast<long long>(m)) - 1;
-          m &= m - 1;
-          const float dl = rdlanef(d, l);
-          const int qi = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-          float* Ld = list_d + (wave * 32 + qi) * KP;
-          int* Li = list_id + (wave * 32 + qi) * KP;
-          if (!(dl < Ld[KP - 1]))
-            continue;
-          const int id = static_cast<int>(row0 + (l & 31));
-          // lane owns entries k = c*64 + lane (c < 4); stable insert: everything <= dl stays,
-          // the first larger entry becomes dl, the rest shift by one
-          float cur[4], prev[4];
-          int previ[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int k = c * kWave + lane;
-            const bool own = k < (int)KP;
-            cur[c] = own ? Ld[k] : inf_f();
-            prev[c] = (own && k > 0) ? Ld[k - 1] : -inf_f();
-            previ[c] = (own && k > 0) ? Li[k - 1] : kEmptyKey;
-          }
-          // one wave: the loads above are issued for all lanes before the stores below (LDS
-          // operations of a wave execute in order); only the compiler must not reorder them
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int k = c * kWave + lane;
-            if (k < (int)KP && dl < cur[c]) {
-              const bool first = !(dl < prev[c]);  // previous entry stays: insert here
-              Ld[k] = first ? dl : prev[c];
-              Li[k] = first ? id : previ[c];
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+        dd[r] = bf_expand<MODE>(acc[t][r], qn[r], bn, jvalid);
+        any |= __ballot(dd[r] < thr[r]);
       }
+      if (!any)
+        continue;
+      bf_insert_hits(dd, thr, row0, list_d + wave * 32 * KP, list_id + wave * 32 * KP, KP, h);
     }
   }
+  }  // T > 1
 
   // partial results of this base slice
   for (uint32_t i = lane; i < 32 * KP; i += 64) {
@@ -424,7 +541,10 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const uint32_t KP = a.k_query + 8;  // margin against rounding of the expanded distance form
   const uint32_t vec = a.dtype == GGNN_F32 ? 4 : 16;
   // one chunk of 2*Dh columns when the row fits (D <= 128), otherwise chunks of 128 columns
-  const uint32_t Dh = a.D > 128 ? 64 : (((a.D + 1) / 2 + vec / 2 - 1) / (vec / 2) * (vec / 2) + 3) / 4 * 4;
+  // half-row width: 64 when D > 128 (K streams in chunks), otherwise 32 / 48 / 64 so that the
+  // single chunk covers the row (columns past D are zero in the tile and in the query operand)
+  const uint32_t Dh = a.D > 128 ? 64 : (a.D <= 64 ? 32 : a.D <= 96 ? 48 : 64);
+  (void)vec;
   const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
   const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
   // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
@@ -486,21 +606,15 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                        static_cast<const T*>(a.base), a.N_base, a.D, bnorm);                      \
     hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,       \
                        static_cast<const T*>(a.query), a.Nq, a.D, qnorm);                         \
+    const void* kern = (a.D > 128) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>)   \
+                       : (Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8>)  \
+                       : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12>) \
+                                    : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 16>);\
     if (lds > 64 * 1024)                                                                          \
-    {                                                                                             \
-      GGNN_HIP_CHECK(hipFuncSetAttribute(                                                         \
-          reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1>),                            \
-          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
-      GGNN_HIP_CHECK(hipFuncSetAttribute(                                                         \
-          reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4>),                            \
-          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                    \
-    }                                                                                             \
-    if (a.D > 128)                                                                                \
-      hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_, 4>), dim3(qblocks, slices), dim3(256), lds,    \
-                         stream, m);                                                              \
-    else                                                                                          \
-      hipLaunchKernelGGL((bf_mfma_kernel<T, MODE_, 1>), dim3(qblocks, slices), dim3(256), lds,    \
-                         stream, m);                                                              \
+      GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                         static_cast<int>(lds)));                                 \
+    void* kargs[] = {&m};                                                                         \
+    GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds, stream));  \
   } while (0)
   if (a.dtype == GGNN_F32) {
     if (a.measure == GGNN_EUCLIDEAN)

@@ -544,9 +544,25 @@ struct ggnn_handle {
       sh.ps_state = 0;  // the codes belong to the other measure: code again
     if (sh.ps_state == 0) {
       const uint32_t Dc = prescreen_code_dim(pad_D);
-      sh.ps_codes.alloc(static_cast<size_t>(cfg.N) * Dc);
-      sh.ps_params.alloc(prescreen_param_floats(pad_D) * 4);
-      DeviceBuffer scratch(prescreen_scratch_floats(cfg.N, pad_D, measure) * 4);
+      DeviceBuffer scratch;
+      try {
+        sh.ps_codes.alloc(static_cast<size_t>(cfg.N) * Dc);
+        sh.ps_params.alloc(prescreen_param_floats(pad_D) * 4);
+        scratch.alloc(prescreen_scratch_floats(cfg.N, pad_D, measure) * 4);
+      }
+      catch (const Error& e) {
+        if (e.status != GGNN_OUT_OF_MEMORY)
+          throw;
+        // an optional copy: without room for it the kernels read the float rows as before
+        (void)hipGetLastError();
+        sh.ps_codes.release();
+        sh.ps_params.release();
+        sh.ps_state = -1;
+        sh.ps_measure = measure;
+        GGNN_LOG(0, "[GPU: %d] no memory for the pre-screen copy of part %u, continuing without",
+                 ctx.device, sh.global_id);
+        return false;
+      }
       launch_prescreen_encode(static_cast<const float*>(shard_base(ctx, si)), cfg.N, pad_D, measure,
                               sh.ps_codes.as<uint8_t>(), sh.ps_params.as<float>(),
                               scratch.as<float>(), ctx.stream);
