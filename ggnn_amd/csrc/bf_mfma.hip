@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
         const float* bt = lds_f + (p & 1) * tile_floats + j * a.DP + h * a.Dh;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          if (static_cast<uint32_t>(4 * u) < a.Dh) {
+          if (u < NU) {  // Dh = 4*NU = 64 on this path
             const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc[t], 0, 0, 0);
