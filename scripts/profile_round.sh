@@ -13,6 +13,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAV
   -d $R/gpurun_out/pmc_sq1_$tag -o bench -- $short > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv \
   -d $R/gpurun_out/pmc_sq2_$tag -o bench -- $short > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv \
+  -d $R/gpurun_out/pmc_mfma_$tag -o bench -- $short > /dev/null 2>&1
 cd $R && tail -1 gpurun_out/bench_prof.json > gpurun_out/bench_prof.tmp && mv gpurun_out/bench_prof.tmp gpurun_out/bench_prof.json
 find gpurun_out -name "*_counter_collection.csv" -o -name "*kernel_stats.csv" | head -20
 python scripts/summarize_profile.py $tag

@@ -61,6 +61,32 @@ if sq:
                         "clocks, so VALU utilisation = SQ_ACTIVE_INST_VALU / (kernel time x "
                         "clock / 4 x 1024 SIMDs)",
                "kernels": sq}, open(f"{out_dir}/{tag}_pmc_sq.json", "w"), indent=1)
+
+# MFMA counters of the brute-force kernel
+path = f"{src}/pmc_mfma_{tag}/bench_counter_collection.csv"
+if os.path.exists(path):
+    c = collections.defaultdict(list)
+    dur = []
+    for r in csv.DictReader(open(path)):
+        if "bf_mfma_kernel" in r["Kernel_Name"]:
+            c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    if c:
+        cnt = {k: sum(v) / len(v) for k, v in c.items()}
+        d = sum(dur) / len(dur)
+        busy = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        json.dump({"command": "rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
+                              "SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -- "
+                              "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+                   "kernel": "bf_mfma_kernel<float, L2, T=1, NU=16> (10 000 x 1 000 000 x 128 f32, k=10)",
+                   "counters": cnt, "kernel_duration_s_under_profiling": d,
+                   "expected_mfma_busy_cycles": "2*Nq_padded*N*D / 4096 flop per "
+                       "v_mfma_f32_32x32x2_f32 * 64 cycles = 10112*1e6*128*2/4096*64 = 4.045e10",
+                   "mfma_utilisation_lower_bound_at_2.4GHz": busy / (1024 * 2.4e9 * d),
+                   "note": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; the effective "
+                           "clock under load is below 2.4 GHz (DVFS), so the true busy fraction "
+                           "is higher"},
+                  open(f"{out_dir}/{tag}_pmc_mfma_bf_query.json", "w"), indent=1)
 print(open(f"{out_dir}/{tag}_kernel_stats.csv").read()[:1500])
 for k, v in pmc.items():
     if "query_kernel" in k and "bf_" not in k and "FETCH_SIZE" in v:
