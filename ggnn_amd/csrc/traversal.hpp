@@ -340,13 +340,21 @@ struct SortedList {
     };
     unsigned acc0 = 0xffffffffu, acc1 = 0xffffffffu;
     const int4* p = kp + h;
-    const int T = (E + 7) >> 3;
+    const int T = (E + 7) >> 3;  // >= 4: SORTED >= 32
+    // the reads of the next pair are issued before the current pair is folded: a lone wave
+    // (small batches, tail of a launch) otherwise pays one LDS latency per pair
+    int4 e0 = p[0], e1 = p[2];
     int t = 0;
-    for (; t + 2 <= T; t += 2) {
-      const int4 e0 = p[2 * t], e1 = p[2 * t + 2];
+    for (; t + 4 <= T; t += 2) {
+      const int4 n0 = p[2 * t + 4], n1 = p[2 * t + 6];
       acc0 = fold(acc0, e0);
       acc1 = fold(acc1, e1);
+      e0 = n0;
+      e1 = n1;
     }
+    acc0 = fold(acc0, e0);
+    acc1 = fold(acc1, e1);
+    t += 2;
     if (t < T)
       acc0 = fold(acc0, p[2 * t]);
     const unsigned acc = min(acc0, acc1);
