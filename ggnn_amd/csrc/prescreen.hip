@@ -304,7 +304,7 @@ void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t 
   else if (chunks <= 16)
     GGNN_PROBE(8, 2);
   else if (chunks <= 64)
-    GGNN_PROBE(16, 4);
+    GGNN_PROBE(32, 2);
   else
     GGNN_PROBE(64, 4);
 #undef GGNN_PROBE

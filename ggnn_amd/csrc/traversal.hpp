@@ -886,7 +886,7 @@ struct PsFor<16, 4, MODE> {
 };
 template <int MODE>
 struct PsFor<64, 4, MODE> {
-  using type = Prescreen<16, 4, MODE>;
+  using type = Prescreen<32, 2, MODE>;  // fewer registers than <16, 4> (2 instead of 4 chunks/lane)
 };
 template <int MODE>
 struct PsFor<64, 16, MODE> {
