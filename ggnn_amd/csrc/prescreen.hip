@@ -302,7 +302,7 @@ void launch_prescreen_probe(const uint8_t* codes, const float* params, uint32_t 
   if (chunks <= 8)
     GGNN_PROBE(8, 1);
   else if (chunks <= 16)
-    GGNN_PROBE(8, 2);
+    GGNN_PROBE(16, 1);
   else if (chunks <= 64)
     GGNN_PROBE(32, 2);
   else

@@ -882,7 +882,7 @@ struct PsFor {
 };
 template <int MODE>
 struct PsFor<16, 4, MODE> {
-  using type = Prescreen<8, 2, MODE>;
+  using type = Prescreen<16, 1, MODE>;
 };
 template <int MODE>
 struct PsFor<64, 4, MODE> {
@@ -900,8 +900,9 @@ template <class PS>
 GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s_thr,
                             const int32_t* translation)
 {
-  // 3 x 8 rows cover the usual KBuild = 24 neighbours of a graph row in one round
-  constexpr int STEPS = (PS::NCH == 1) ? 3 : StepsOf<PS::LPR, PS::NCH>::value;
+  // one-chunk layouts keep the usual KBuild = 24 neighbours of a graph row in flight in one round
+  constexpr int STEPS = (PS::NCH == 1 && PS::ROWS <= 8) ? 24 / PS::ROWS
+                                                        : StepsOf<PS::LPR, PS::NCH>::value;
   constexpr int ROWS = PS::ROWS;
   const int lane = threadIdx.x;
   const int grp = lane / PS::LPR;
