@@ -945,9 +945,16 @@ GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s
 // fetch(): simple_knn_cache.cuh:241-289.  cand: lane j (<32) holds candidate key j or EMPTY.
 // Returns the number of distance evaluations (of the reference: pre-screened candidates count);
 // rows.x / rows.y are advanced by the numbers of float / code rows actually read.
-template <int MODE, bool FILTER, class SL, class DE, class PS>
+// after_filter(): hook called once the candidate keys have been consumed by the filter -- the
+// place for a caller's own prefetch: a load issued BEFORE fetch() is waited for together with the
+// candidates' graph row (the compiler merges the waits to vmcnt(0)), i.e. not overlapped at all.
+struct NoHook {
+  GGNN_DEV void operator()() const {}
+};
+template <int MODE, bool FILTER, class SL, class DE, class PS, class HOOK = NoHook>
 GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
-                   const int32_t* translation, const PS& ps, uint2& rows)
+                   const int32_t* translation, const PS& ps, uint2& rows,
+                   HOOK&& after_filter = NoHook{})
 {
   const int lane = threadIdx.x;
   cand = __shfl(cand, lane & 31);
@@ -955,6 +962,7 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
     cand = sl.filter(cand, lds.known);
   const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
   const int nsurv = __popcll(surv);
+  after_filter();
   if (nsurv == 0)
     return 0;
   __syncthreads();
