@@ -39,7 +39,9 @@ struct BfMfmaArgs {
 };
 
 // ---- 1. squared norms ---------------------------------------------------------------------------
-template <typename BaseT>
+// SHIFT (uint8 only): norms of x - 128, the values the i8 matrix path works on; squared L2
+// distances do not change under a common shift
+template <typename BaseT, bool SHIFT = false>
 __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint32_t N, uint32_t D,
                                                        float* out)
 {
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
       const Chunk v = *reinterpret_cast<const Chunk*>(p + e0);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const float x = ChunkOf<BaseT>::get(v, e);
+        const float x = ChunkOf<BaseT>::get(v, e) - (SHIFT ? 128.f : 0.f);
         acc = fmaf(x, x, acc);
       }
     }
@@ -457,6 +459,151 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
   }
 }
 
+// ---- 2b. uint8 rows, squared L2: the contraction on v_mfma_i32_32x32x32_i8 ------------------------
+// Bytes are shifted to signed (x ^ 0x80 = x - 128), which leaves (q - b)^2 unchanged, so
+// d = |q'|^2 + |b'|^2 - 2 q'.b' with the integer dot product of the shifted bytes: exact (all terms
+// < 2^24 for D <= 128).  Lane (j, h) owns bytes [32m + 16h, 32m + 16h + 16) of row j for MFMA m
+// (any assignment of k to lanes works as long as A and B agree).  A tile of 32 rows is 32 x 128
+// bytes (row stride 144: conflict-free ds_read_b128, the spare bytes hold the row's norm); with 4
+// MFMAs per tile the kernel is bound by staging and the candidate test, not by the matrix pipe.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kBfI8RowStride = 144;
+
+template <int NM>  // MFMAs per tile = ceil(D / 32), D <= 128
+__global__ void __launch_bounds__(256) bf_mfma_i8_kernel(const BfMfmaArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  uint8_t* lds_b = reinterpret_cast<uint8_t*>(lds_f);
+  constexpr uint32_t tile_bytes = kBfTileRows * kBfI8RowStride;
+  float* list_d = lds_f + 2 * tile_bytes / 4;
+  int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const uint8_t* base = static_cast<const uint8_t*>(a.base);
+  const uint8_t* query = static_cast<const uint8_t*>(a.query);
+  const uint32_t qbase = (blockIdx.x * 4 + wave) * 32;
+  const uint32_t begin = blockIdx.y * a.rows_per_slice;
+  const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
+  const uint32_t KP = a.KP;
+
+  for (uint32_t i = lane; i < 32 * KP; i += 64) {
+    list_d[wave * 32 * KP + i] = (qbase + i / KP < a.Nq) ? inf_f() : -inf_f();
+    list_id[wave * 32 * KP + i] = kEmptyKey;
+  }
+
+  // A operand: the lane's 16-byte pieces of query row j, shifted to signed
+  const bool qvalid = qbase + j < a.Nq;
+  const uint8_t* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
+  i32x4 aq[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const uint32_t col = 32 * m + 16 * h;
+    aq[m] = i32x4{0, 0, 0, 0};
+    if (qvalid && col < a.D) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qrow + col);
+      aq[m] = i32x4{static_cast<int>(v.x ^ 0x80808080u), static_cast<int>(v.y ^ 0x80808080u),
+                    static_cast<int>(v.z ^ 0x80808080u), static_cast<int>(v.w ^ 0x80808080u)};
+    }
+  }
+  float qn[16], thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
+    thr[r] = qi < a.Nq ? inf_f() : -inf_f();
+  }
+
+  // staging: thread t moves the 16-byte piece (t % 8) of tile row t / 8; threads 0..31 the norms
+  const uint32_t srow = tid >> 3, scol = 16 * (tid & 7);
+  uint4 sv;
+  float sbn;
+  auto stage_load = [&](uint32_t row0) {
+    sv = make_uint4(0u, 0u, 0u, 0u);
+    if (row0 + srow < end && scol < a.D) {
+      const uint4 v = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + srow) * a.D +
+                                                      scol);
+      sv = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+    }
+    sbn = inf_f();  // rows past the end: +inf distance
+    if (tid < kBfTileRows && row0 + tid < end)
+      sbn = a.bnorm[row0 + tid];
+  };
+  auto stage_store = [&](uint32_t buf) {
+    uint8_t* t = lds_b + buf * tile_bytes;
+    *reinterpret_cast<uint4*>(t + srow * kBfI8RowStride + scol) = sv;
+    if (tid < kBfTileRows)
+      *reinterpret_cast<float*>(t + tid * kBfI8RowStride + 128) = sbn;
+  };
+
+  const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
+  if (ntiles) {
+    stage_load(begin);
+    stage_store(0);
+  }
+  __syncthreads();
+
+  f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bn_prev = inf_f();
+  uint32_t row0_prev = begin;
+  float* wave_d = list_d + wave * 32 * KP;
+  int* wave_id = list_id + wave * 32 * KP;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // see bf_mfma_kernel: no first use of a load inside the loop
+  for (uint32_t tt = 0; tt < ntiles; ++tt) {
+    const uint32_t row0 = begin + tt * kBfTileRows;
+    const uint8_t* t = lds_b + (tt & 1) * tile_bytes + j * kBfI8RowStride;
+    const float bn = *reinterpret_cast<const float*>(t + 128);
+    const bool has_next = tt + 1 < ntiles;
+    if (has_next)
+      stage_load(row0 + kBfTileRows);
+    i32x16 acc = i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const i32x4 b = *reinterpret_cast<const i32x4*>(t + 32 * m + 16 * h);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[m], b, acc, 0, 0, 0);
+    }
+    // candidate test of the previous tile while the matrix pipe works on this one
+    float dd[16];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dd[r] = bf_expand<kL2>(acc_prev[r], qn[r], bn_prev, true);
+      any |= __ballot(dd[r] < thr[r]);
+    }
+    if (any)
+      bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+    if (has_next)
+      stage_store((tt + 1) & 1);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc_prev[r] = static_cast<float>(acc[r]);
+    bn_prev = bn;
+    row0_prev = row0;
+  }
+  if (ntiles) {
+    float dd[16];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dd[r] = bf_expand<kL2>(acc_prev[r], qn[r], bn_prev, true);
+      any |= __ballot(dd[r] < thr[r]);
+    }
+    if (any)
+      bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+  }
+
+  for (uint32_t i = lane; i < 32 * KP; i += 64) {
+    const uint32_t qi = qbase + i / KP;
+    if (qi < a.Nq) {
+      const size_t o = (static_cast<size_t>(blockIdx.y) * a.Nq + qi) * KP + i % KP;
+      a.part_ids[o] = list_id[wave * 32 * KP + i];
+      a.part_dists[o] = list_d[wave * 32 * KP + i];
+    }
+  }
+}
+
 // ---- 3. exact re-rank ----------------------------------------------------------------------------
 struct BfRerankArgs {
   const void* base;
@@ -616,7 +763,29 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     void* kargs[] = {&m};                                                                         \
     GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds, stream));  \
   } while (0)
-  if (a.dtype == GGNN_F32) {
+  // uint8 + squared L2 with rows of up to 128 bytes: integer contraction (bf_mfma_i8_kernel)
+  const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
+                      std::getenv("GGNN_BF_NO_I8") == nullptr;
+  if (use_i8) {
+    hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
+                       grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(a.base), a.N_base, a.D, bnorm);
+    hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
+                       grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,
+                       static_cast<const uint8_t*>(a.query), a.Nq, a.D, qnorm);
+    const size_t lds8 = 2 * kBfTileRows * kBfI8RowStride + 2 * kBfQueriesPerBlock * KP * sizeof(float);
+    const uint32_t nm = (a.D + 31) / 32;
+    const void* kern = nm == 1   ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<1>)
+                       : nm == 2 ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<2>)
+                       : nm == 3 ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<3>)
+                                 : reinterpret_cast<const void*>(&bf_mfma_i8_kernel<4>);
+    if (lds8 > 64 * 1024)
+      GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds8)));
+    void* kargs[] = {&m};
+    GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds8, stream));
+  }
+  else if (a.dtype == GGNN_F32) {
     if (a.measure == GGNN_EUCLIDEAN)
       GGNN_BF_MFMA(float, kL2);
     else

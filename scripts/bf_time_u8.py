@@ -1,0 +1,19 @@
+"""bf_query timing for uint8 rows (10k x 1M x 128, k=10)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ggnn_amd import ops
+from bench import synthetic
+dev = torch.device("cuda", 0)
+base = synthetic("lowrank16", 1_000_000, 128, 1234, dev).to(torch.uint8)
+query = synthetic("lowrank16", 10_000, 128, 4321, dev).to(torch.uint8)
+for _ in range(2):
+    ids, d = ops.bf_query(base, query, 10)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    ids, d = ops.bf_query(base, query, 10)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"bf_query u8 D=128: {ms:.2f} ms  {2*1e4*1e6*128/ms/1e9:.1f} Top/s")

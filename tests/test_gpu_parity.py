@@ -90,6 +90,26 @@ def test_bf_query_uint8(ops, orc):
     assert np.array_equal(d.cpu().numpy(), o_d)
 
 
+@pytest.mark.parametrize("N,D,Nq,K", [(9000, 128, 300, 10), (5000, 64, 257, 10), (7000, 96, 300, 24),
+                                      (4100, 32, 260, 5), (6000, 112, 300, 100), (40000, 128, 512, 10)])
+def test_bf_query_uint8_matrix_path(ops, orc, N, D, Nq, K):
+    """uint8 + L2 with >= 256 queries and >= 4096 rows runs on v_mfma_i32_32x32x32_i8 (bytes
+    shifted to signed); extreme byte values and duplicated rows included"""
+    rng = np.random.default_rng(N + D)
+    base = rng.integers(0, 256, (N, D)).astype(np.uint8)
+    base[::97] = 255
+    base[5::101] = 0
+    base[N // 2:N // 2 + 50] = base[:50]  # ties: the lower index comes first
+    q = rng.integers(0, 256, (Nq, D)).astype(np.uint8)
+    q[3] = 0
+    q[4] = 255
+    q[5] = base[7]
+    ids, d = ops.bf_query(dev(base), dev(q), K)
+    o_ids, o_d = orc.bf_query(base, q, K)
+    assert np.array_equal(ids.cpu().numpy(), o_ids)
+    assert np.array_equal(d.cpu().numpy(), o_d)
+
+
 # ---------------------------------------------------------------------------------------------
 # query
 # ---------------------------------------------------------------------------------------------
