@@ -97,15 +97,31 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
       const int cand = (lane == 0) ? n : kEmptyKey;
       cnt_dist += fetch<MODE, false>(sl, de, lds, cand, tr, ps, rows_read);
     }
+    // graph row of the queue head loaded ahead (query.hip: same speculation, same hook)
+    int spec_key = kEmptyKey, spec_row = kEmptyKey;
+    const int32_t* layer_graph = a.graph_all + static_cast<size_t>(a.Ns_off[layer]) * K;
     for (uint32_t ite = 0; ite < kMergeIterations; ++ite) {
       const int anchor = sl.pop(sl.criteria(), lds.known);
       if (anchor == kEmptyKey)
         break;
-      const int32_t* row =
-          a.graph_all + (static_cast<size_t>(a.Ns_off[layer]) + static_cast<uint32_t>(anchor)) * K;
+      const int32_t* row = layer_graph + static_cast<size_t>(static_cast<uint32_t>(anchor)) * K;
       for (uint32_t j = 0; j < K; j += kKBlock) {
-        const int cand = (lane < (int)kKBlock && j + lane < K) ? row[j + lane] : kEmptyKey;
-        cnt_dist += fetch<MODE, true>(sl, de, lds, cand, tr, ps, rows_read);
+        const bool in_row = lane < (int)kKBlock && j + lane < K;
+        int cand;
+        if (j == 0 && anchor == spec_key)
+          cand = spec_row;
+        else
+          cand = in_row ? row[j + lane] : kEmptyKey;
+        auto prefetch_head_row = [&]() {
+          if (j == 0) {
+            spec_key = sl.key_at(sl.BEST);
+            if (spec_key != kEmptyKey)
+              spec_row = in_row ? layer_graph[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
+                                                  K + lane]
+                                : kEmptyKey;
+          }
+        };
+        cnt_dist += fetch<MODE, true>(sl, de, lds, cand, tr, ps, rows_read, prefetch_head_row);
       }
     }
   }
