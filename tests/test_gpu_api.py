@@ -338,3 +338,27 @@ def test_prescreen_follows_the_measure():
             assert np.array_equal(res[(measure, enable)][0], np.asarray(ids))
         assert np.array_equal(res[(measure, True)][0], res[(measure, False)][0])
         assert np.array_equal(res[(measure, True)][1], res[(measure, False)][1])
+
+
+@pytest.mark.parametrize("D,measure", [(100, 0), (100, 1), (67, 0)])
+def test_prescreen_with_padded_rows(D, measure):
+    # rows that the engine pads to a multiple of 16 bytes (and the codes to 16 dimensions)
+    import ggnn_amd as ggnn
+    rng = np.random.default_rng(8)
+    centres = rng.normal(size=(16, D)) * 3
+    base = (centres[rng.integers(0, 16, 5000)] + rng.normal(size=(5000, D))).astype(np.float32)
+    q = (centres[rng.integers(0, 16, 150)] + rng.normal(size=(150, D))).astype(np.float32)
+    base[11] = 0.0
+    g = ggnn.GGNN()
+    g.set_collect_counters(True)
+    g.set_base(base)
+    g.build(24, 0.5, 1, measure)
+    res = []
+    for enable in (True, False):
+        g.set_prescreen(enable)
+        ids, d = g.query(q, 10, 0.8, 200, measure)
+        res.append((np.asarray(ids), np.asarray(d), g.last_query_counters()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+    rows = g.last_query_rows_read()
+    assert rows["code_rows"] == 0 and rows["float_rows"] == res[1][2]["n_dist"]

@@ -790,3 +790,23 @@ def test_query_and_merge_prescreened_cosine_equal_plain(ops, orc, maker, D):
         fast = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, top, btm, 1, counters=True, prescreen=ps)
         for x, y in zip(plain, fast):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("K", [20, 40])
+def test_prescreen_other_graph_degrees(ops, orc, K):
+    """KBuild = 40 needs two fetch blocks per pop, KBuild = 20 leaves lanes of a block empty"""
+    N, D = 3000, 128
+    base, q = _clustered(N, D, 121), _clustered(120, D, 122)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, rng=orc.make_rng(N, 11))
+    start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
+    b, qq, ga, ta, sa, ss = dev(base), dev(q), dev(graph), dev(tr), dev(sel), dev(stats)
+    ps = ops.prescreen_encode(b)
+    plain = ops.query(b, qq, dev(graph[:N]), dev(start), ss, 10, 0.7, 200, counters=True)
+    fast = ops.query(b, qq, dev(graph[:N]), dev(start), ss, 10, 0.7, 200, counters=True,
+                     prescreen=ps)
+    for x, y in zip(plain, fast):
+        assert torch.equal(x, y)
+    plain = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, 3, 0, counters=True)
+    fast = ops.merge(b, cfg, ga, ta, sa, ss, 0.5, 3, 0, counters=True, prescreen=ps)
+    for x, y in zip(plain, fast):
+        assert torch.equal(x, y)
