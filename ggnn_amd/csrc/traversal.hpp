@@ -541,6 +541,7 @@ struct DistEngine {
   const BaseT* base;
   uint32_t D;
   int g;  // lane within the row group
+  bool all_chunks;  // wave-uniform: the row fills every chunk of every lane (e.g. D = 128 f32)
   Chunk q[NCH];
   float q_norm;    // cosine: |q|^2
   uint32_t qq_u8;  // uint8 rows: sum of squares of this lane's query elements
@@ -565,6 +566,7 @@ struct DistEngine {
     base = base_;
     D = D_;
     g = threadIdx.x % LPR;
+    all_chunks = D_ == static_cast<uint32_t>(LPR * NCH * EPC);
     float nrm = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -674,24 +676,26 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
       const int r = s0 + s * ROWS + grp;
       const bool valid = r < nsurv;
       rr[s] = valid ? r : -1;
-      int m = 0;
-      if (valid) {
-        m = lds.ckeys[r];
-        if (translation)
-          m = translation[m];
-      }
+      // slots past the end read the row of the first candidate (cached, result never stored):
+      // no branch and no zero-fill around the loads
+      int m = lds.ckeys[valid ? r : s0];
+      if (translation)
+        m = translation[m];
       const auto* row = de.row_ptr(m);
 #pragma unroll
       for (int c = 0; c < DE::NCH; ++c) {
-        v[s][c] = ChunkOf<typename DE::Base>::zero();
-        if (valid && de.chunk_valid(c))
+        if (de.all_chunks || de.chunk_valid(c))
           v[s][c] = de.load_chunk(row, c);
+        else
+          v[s][c] = ChunkOf<typename DE::Base>::zero();
       }
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (s0 + s * ROWS >= nsurv)
         break;  // wave-uniform: no rows left for this and the following steps
+      if (s > 0)
+        asm volatile("" ::: "memory");  // keep the branch: the later steps are usually empty
       float a, b;
       de.template partial<MODE>(v[s], a, b);
       a = group_sum<DE::LPR>(a);
@@ -750,6 +754,7 @@ struct Prescreen {
   uint32_t qq;    // sum of their squares
   float inv_s, slack, m;
   bool usable;
+  bool all_chunks;  // wave-uniform: the code row fills every chunk of every lane
 
   GGNN_DEV bool chunk_valid(int c) const
   {
@@ -771,6 +776,7 @@ struct Prescreen {
     codes = codes_;
     Dc = Dc_;
     g = threadIdx.x % LPR;
+    all_chunks = Dc_ == static_cast<uint32_t>(LPR * NCH * 16);
     inv_s = params[1];
     const float* offs = params + kPsHeader;
     constexpr float u = 5.9604645e-8f;  // 2^-24
@@ -868,7 +874,8 @@ struct Prescreen {
       return inf_f();
     if (MODE_ == kCos)
       crit = 2.f * (crit + m) * (1.f + m);
-    float t = sqrtf(crit) * (1.f + m) + slack;
+    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: m >= 32 * 4 * 2^-24 covers it
+    float t = __builtin_amdgcn_sqrtf(crit) * (1.f + m) + slack;
     t = t * inv_s * (1.f + m);
     return t * t * (1.f + m);
   }
@@ -914,16 +921,18 @@ GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s
     for (int s = 0; s < STEPS; ++s) {
       const int r = s0 + s * ROWS + grp;
       const bool valid = r < nsurv;
-      kk[s] = valid ? lds.ckeys[r] : kEmptyKey;
-      int m = valid ? kk[s] : 0;
-      if (valid && translation)
+      // slots past the end read the code row of the first candidate (cached, verdict ignored)
+      int m = lds.ckeys[valid ? r : s0];
+      kk[s] = valid ? m : kEmptyKey;
+      if (translation)
         m = translation[m];
       const uint8_t* row = ps.row_ptr(m);
 #pragma unroll
       for (int c = 0; c < PS::NCH; ++c) {
-        v[s][c] = make_uint4(0u, 0u, 0u, 0u);
-        if (valid && ps.chunk_valid(c))
+        if (ps.all_chunks || ps.chunk_valid(c))
           v[s][c] = ps.load_chunk(row, c);
+        else
+          v[s][c] = make_uint4(0u, 0u, 0u, 0u);
       }
     }
     __syncthreads();  // all keys of this round are in registers before the in-place compaction
