@@ -142,18 +142,17 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
       const int r = s0 + s * ROWS + grp;
       const bool valid = r < nsurv;
       rr[s] = valid ? r : -1;
-      int m = 0;
-      if (valid) {
-        m = lds.ckeys[r];
-        if (translation)
-          m = translation[m];
-      }
+      // slots past the end read the row of the first candidate (cached, result never stored)
+      int m = lds.ckeys[valid ? r : s0];
+      if (translation)
+        m = translation[m];
       const auto* row = se.row_ptr(m);
 #pragma unroll
       for (int c = 0; c < SE::NCH; ++c) {
-        v[s][c] = ChunkOf<typename SE::Base>::zero();
-        if (valid && se.chunk_valid(c))
+        if (se.all_chunks || se.chunk_valid(c))
           v[s][c] = se.load_chunk(row, c);
+        else
+          v[s][c] = ChunkOf<typename SE::Base>::zero();
       }
     }
 #pragma unroll
