@@ -245,6 +245,22 @@ def main():
         if not (torch.equal(ids_plain, ids) and torch.equal(dists_plain, dists)):
             raise RuntimeError("pre-screened and plain query results differ")
 
+    # informational: throughput with a batch large enough to keep every SIMD busy to the end
+    # (10k queries are 9.8 waves per SIMD with 7 resident: the tail of the launch runs at low
+    # occupancy); not part of `value`
+    saturated = None
+    if world == 1:
+        big = synthetic(args.dataset, 10 * args.n_query, args.dim, 9876, device)
+        for _ in range(2):
+            eng.query(big, args.k, args.tau_query, args.max_iters)
+        sat_ms = []
+        for _ in range(3):
+            eng.query(big, args.k, args.tau_query, args.max_iters)
+            sat_ms.append(eng.last_timing_ms()["query_ms"])
+        saturated = {"n_query": int(big.shape[0]), "query_kernel_ms": float(np.mean(sat_ms)),
+                     "queries_per_s": big.shape[0] / (float(np.mean(sat_ms)) * 1e-3)}
+        del big
+
     if rank == 0:
         nq, d, k = args.n_query, args.dim, args.k
         ms_per_step = elapsed / args.steps * 1000.0
@@ -294,6 +310,7 @@ def main():
             "query_kernel_ms": avg_kernel_ms,
             "n_dist_per_query": cnt["n_dist"] / nq,
             "n_pop_per_query": cnt["n_pop"] / nq,
+            "saturated_batch": saturated,
             "float_rows_per_query": rows["float_rows"] / nq,
             "code_rows_per_query": rows["code_rows"] / nq,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
