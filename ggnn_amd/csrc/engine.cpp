@@ -69,13 +69,38 @@ struct DeviceBuffer {
   }
 };
 
+// HIP-event stopwatch on one stream.  The two events are created once per host thread and
+// reused (event creation and destruction cost ~10 us per query() otherwise).
 struct EventTimer {
   hipEvent_t a{}, b{};
   hipStream_t s;
   explicit EventTimer(hipStream_t stream) : s(stream)
   {
-    GGNN_HIP_CHECK(hipEventCreate(&a));
-    GGNN_HIP_CHECK(hipEventCreate(&b));
+    struct Pair {
+      hipEvent_t a{}, b{};
+      int device{-1};
+      ~Pair()
+      {
+        if (device >= 0) {
+          (void)hipEventDestroy(a);
+          (void)hipEventDestroy(b);
+        }
+      }
+    };
+    static thread_local Pair cache;
+    int dev = 0;
+    GGNN_HIP_CHECK(hipGetDevice(&dev));
+    if (cache.device != dev) {
+      if (cache.device >= 0) {
+        (void)hipEventDestroy(cache.a);
+        (void)hipEventDestroy(cache.b);
+      }
+      GGNN_HIP_CHECK(hipEventCreate(&cache.a));
+      GGNN_HIP_CHECK(hipEventCreate(&cache.b));
+      cache.device = dev;
+    }
+    a = cache.a;
+    b = cache.b;
     GGNN_HIP_CHECK(hipEventRecord(a, s));
   }
   float stop()
@@ -85,11 +110,6 @@ struct EventTimer {
     GGNN_HIP_CHECK(hipEventSynchronize(b));
     GGNN_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     return ms;
-  }
-  ~EventTimer()
-  {
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
   }
 };
 
