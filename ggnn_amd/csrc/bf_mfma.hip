@@ -464,19 +464,24 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
 // d = |q'|^2 + |b'|^2 - 2 q'.b' with the integer dot product of the shifted bytes: exact (all terms
 // < 2^24 for D <= 128).  Lane (j, h) owns bytes [32m + 16h, 32m + 16h + 16) of row j for MFMA m
 // (any assignment of k to lanes works as long as A and B agree).  A tile of 32 rows is 32 x 128
-// bytes (row stride 144: conflict-free ds_read_b128, the spare bytes hold the row's norm); with 4
-// MFMAs per tile the kernel is bound by staging and the candidate test, not by the matrix pipe.
+// bytes (row stride 144: conflict-free ds_read_b128, the spare bytes hold the row's norm); four
+// tiles are staged per barrier.  With 4 MFMAs per tile the kernel is bound by staging and the
+// candidate test, not by the matrix pipe.
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kBfI8RowStride = 144;
+
+constexpr int kBfI8Tiles = 4;  // 32-row tiles per staged block (one barrier per 128 base rows)
 
 template <int NM>  // MFMAs per tile = ceil(D / 32), D <= 128
 __global__ void __launch_bounds__(256) bf_mfma_i8_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   uint8_t* lds_b = reinterpret_cast<uint8_t*>(lds_f);
-  constexpr uint32_t tile_bytes = kBfTileRows * kBfI8RowStride;
-  float* list_d = lds_f + 2 * tile_bytes / 4;
+  constexpr int TT = kBfI8Tiles;
+  constexpr uint32_t stage_rows = TT * kBfTileRows;
+  constexpr uint32_t stage_bytes = stage_rows * kBfI8RowStride;
+  float* list_d = lds_f + 2 * stage_bytes / 4;
   int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -515,83 +520,83 @@ __global__ void __launch_bounds__(256) bf_mfma_i8_kernel(const BfMfmaArgs a)
     thr[r] = qi < a.Nq ? inf_f() : -inf_f();
   }
 
-  // staging: thread t moves the 16-byte piece (t % 8) of tile row t / 8; threads 0..31 the norms
-  const uint32_t srow = tid >> 3, scol = 16 * (tid & 7);
-  uint4 sv;
+  // staging: a block of 128 rows is 1024 pieces of 16 bytes, 4 per thread; threads 0..127 carry
+  // the row norms (+inf for rows past the end: +inf distance)
+  uint4 sv[TT];
   float sbn;
   auto stage_load = [&](uint32_t row0) {
-    sv = make_uint4(0u, 0u, 0u, 0u);
-    if (row0 + srow < end && scol < a.D) {
-      const uint4 v = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + srow) * a.D +
-                                                      scol);
-      sv = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+#pragma unroll
+    for (int e = 0; e < TT; ++e) {
+      const uint32_t p = tid + 256 * e, srow = p >> 3, scol = 16 * (p & 7);
+      sv[e] = make_uint4(0u, 0u, 0u, 0u);
+      if (row0 + srow < end && scol < a.D) {
+        const uint4 v = *reinterpret_cast<const uint4*>(
+            base + static_cast<size_t>(row0 + srow) * a.D + scol);
+        sv[e] = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u,
+                           v.w ^ 0x80808080u);
+      }
     }
-    sbn = inf_f();  // rows past the end: +inf distance
-    if (tid < kBfTileRows && row0 + tid < end)
+    sbn = inf_f();
+    if (tid < (int)stage_rows && row0 + tid < end)
       sbn = a.bnorm[row0 + tid];
   };
   auto stage_store = [&](uint32_t buf) {
-    uint8_t* t = lds_b + buf * tile_bytes;
-    *reinterpret_cast<uint4*>(t + srow * kBfI8RowStride + scol) = sv;
-    if (tid < kBfTileRows)
+    uint8_t* t = lds_b + buf * stage_bytes;
+#pragma unroll
+    for (int e = 0; e < TT; ++e) {
+      const uint32_t p = tid + 256 * e, srow = p >> 3, scol = 16 * (p & 7);
+      *reinterpret_cast<uint4*>(t + srow * kBfI8RowStride + scol) = sv[e];
+    }
+    if (tid < (int)stage_rows)
       *reinterpret_cast<float*>(t + tid * kBfI8RowStride + 128) = sbn;
   };
 
-  const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
-  if (ntiles) {
+  const uint32_t nstages = (end > begin) ? (end - begin + stage_rows - 1) / stage_rows : 0;
+  if (nstages) {
     stage_load(begin);
     stage_store(0);
   }
   __syncthreads();
 
-  f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float bn_prev = inf_f();
-  uint32_t row0_prev = begin;
   float* wave_d = list_d + wave * 32 * KP;
   int* wave_id = list_id + wave * 32 * KP;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // see bf_mfma_kernel: no first use of a load inside the loop
-  for (uint32_t tt = 0; tt < ntiles; ++tt) {
-    const uint32_t row0 = begin + tt * kBfTileRows;
-    const uint8_t* t = lds_b + (tt & 1) * tile_bytes + j * kBfI8RowStride;
-    const float bn = *reinterpret_cast<const float*>(t + 128);
-    const bool has_next = tt + 1 < ntiles;
+  for (uint32_t st = 0; st < nstages; ++st) {
+    const uint32_t row0 = begin + st * stage_rows;
+    const uint8_t* blk = lds_b + (st & 1) * stage_bytes;
+    const bool has_next = st + 1 < nstages;
     if (has_next)
-      stage_load(row0 + kBfTileRows);
-    i32x16 acc = i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      stage_load(row0 + stage_rows);
+    i32x16 acc[TT];
+    float bn[TT];
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const i32x4 b = *reinterpret_cast<const i32x4*>(t + 32 * m + 16 * h);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[m], b, acc, 0, 0, 0);
-    }
-    // candidate test of the previous tile while the matrix pipe works on this one
-    float dd[16];
-    unsigned long long any = 0;
+    for (int t = 0; t < TT; ++t) {
+      const uint8_t* trow = blk + (t * kBfTileRows + j) * kBfI8RowStride;
+      bn[t] = *reinterpret_cast<const float*>(trow + 128);
+      acc[t] = i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dd[r] = bf_expand<kL2>(acc_prev[r], qn[r], bn_prev, true);
-      any |= __ballot(dd[r] < thr[r]);
+      for (int m = 0; m < NM; ++m) {
+        const i32x4 b = *reinterpret_cast<const i32x4*>(trow + 32 * m + 16 * h);
+        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[m], b, acc[t], 0, 0, 0);
+      }
     }
-    if (any)
-      bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (row0 + t * kBfTileRows >= end)
+        break;  // uniform
+      float dd[16];
+      unsigned long long any = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dd[r] = bf_expand<kL2>(static_cast<float>(acc[t][r]), qn[r], bn[t], true);
+        any |= __ballot(dd[r] < thr[r]);
+      }
+      if (any)
+        bf_insert_hits(dd, thr, row0 + t * kBfTileRows, wave_d, wave_id, KP, h);
+    }
     if (has_next)
-      stage_store((tt + 1) & 1);
+      stage_store((st + 1) & 1);
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc_prev[r] = static_cast<float>(acc[r]);
-    bn_prev = bn;
-    row0_prev = row0;
-  }
-  if (ntiles) {
-    float dd[16];
-    unsigned long long any = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dd[r] = bf_expand<kL2>(acc_prev[r], qn[r], bn_prev, true);
-      any |= __ballot(dd[r] < thr[r]);
-    }
-    if (any)
-      bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
   }
 
   for (uint32_t i = lane; i < 32 * KP; i += 64) {
@@ -773,7 +778,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
                        grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.query), a.Nq, a.D, qnorm);
-    const size_t lds8 = 2 * kBfTileRows * kBfI8RowStride + 2 * kBfQueriesPerBlock * KP * sizeof(float);
+    const size_t lds8 = 2 * kBfI8Tiles * kBfTileRows * kBfI8RowStride +
+                        2 * kBfQueriesPerBlock * KP * sizeof(float);
     const uint32_t nm = (a.D + 31) / 32;
     const void* kern = nm == 1   ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<1>)
                        : nm == 2 ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<2>)
