@@ -32,15 +32,15 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
     ps.load(a.ps_codes, a.ps_params, a.ps_Dc, reinterpret_cast<const float*>(qrow), a.D);
 }
 
-// occupancy target of the common instantiations (one register of list per lane, narrow rows,
-// pre-screen): a tuning knob, 1 = leave it to the compiler
+// occupancy target of the common instantiations (one register of list per lane, narrow rows):
+// a tuning knob, 1 = leave it to the compiler
 #ifndef GGNN_QUERY_WAVES
 #define GGNN_QUERY_WAVES 7
 #endif
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 2 && PSC::enabled) ? GGNN_QUERY_WAVES : 1)))
+    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
 query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
