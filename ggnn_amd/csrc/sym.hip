@@ -185,7 +185,9 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
 }
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE>
-__global__ void __launch_bounds__(kWave) sym_kernel(const SymArgs a)
+// one-chunk layouts fit 7 waves per SIMD without spilling (79 -> 71 registers for uint8 rows)
+__global__ void __launch_bounds__(kWave)
+    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH == 1) ? 7 : 1))) sym_kernel(const SymArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kSymCache);
