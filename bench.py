@@ -147,6 +147,10 @@ def main():
     ap.add_argument("--max-iters", type=int, default=200)
     ap.add_argument("--dataset", default="lowrank16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--saturated-batch", action="store_true",
+                    help="also time a 10x larger query batch (informational; off by default so "
+                         "that a rocprofv3 --stats of the default command averages only "
+                         "launches of the benchmark's own batch size)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (needs --backend gloo)")
@@ -249,7 +253,7 @@ def main():
     # (10k queries are 9.8 waves per SIMD with 7 resident: the tail of the launch runs at low
     # occupancy); not part of `value`
     saturated = None
-    if world == 1:
+    if world == 1 and args.saturated_batch:
         big = synthetic(args.dataset, 10 * args.n_query, args.dim, 9876, device)
         for _ in range(2):
             eng.query(big, args.k, args.tau_query, args.max_iters)
