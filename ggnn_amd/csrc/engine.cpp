@@ -69,38 +69,13 @@ struct DeviceBuffer {
   }
 };
 
-// HIP-event stopwatch on one stream.  The two events are created once per host thread and
-// reused (event creation and destruction cost ~10 us per query() otherwise).
+// HIP-event stopwatch on one stream, on two events owned by the caller (DeviceCtx creates them
+// once: creating and destroying events costs ~10 us per query() otherwise)
 struct EventTimer {
-  hipEvent_t a{}, b{};
+  hipEvent_t a, b;
   hipStream_t s;
-  explicit EventTimer(hipStream_t stream) : s(stream)
+  EventTimer(hipStream_t stream, hipEvent_t ev_a, hipEvent_t ev_b) : a(ev_a), b(ev_b), s(stream)
   {
-    struct Pair {
-      hipEvent_t a{}, b{};
-      int device{-1};
-      ~Pair()
-      {
-        if (device >= 0) {
-          (void)hipEventDestroy(a);
-          (void)hipEventDestroy(b);
-        }
-      }
-    };
-    static thread_local Pair cache;
-    int dev = 0;
-    GGNN_HIP_CHECK(hipGetDevice(&dev));
-    if (cache.device != dev) {
-      if (cache.device >= 0) {
-        (void)hipEventDestroy(cache.a);
-        (void)hipEventDestroy(cache.b);
-      }
-      GGNN_HIP_CHECK(hipEventCreate(&cache.a));
-      GGNN_HIP_CHECK(hipEventCreate(&cache.b));
-      cache.device = dev;
-    }
-    a = cache.a;
-    b = cache.b;
     GGNN_HIP_CHECK(hipEventRecord(a, s));
   }
   float stop()
@@ -160,6 +135,7 @@ using namespace ggnn_amd;
 struct DeviceCtx {
   int device{0};
   hipStream_t stream{nullptr};
+  hipEvent_t ev_a{nullptr}, ev_b{nullptr};  // timing events, created with the stream
   DeviceBuffer base_copy;       // this GPU's slice of the base unless it is borrowed
   const void* d_base{nullptr};  // first row of the slice
   uint32_t first_shard{0};      // global id of shards[0]
@@ -175,7 +151,10 @@ struct DeviceCtx {
   {
     device = o.device;
     stream = o.stream;
+    ev_a = o.ev_a;
+    ev_b = o.ev_b;
     o.stream = nullptr;
+    o.ev_a = o.ev_b = nullptr;
     base_copy = std::move(o.base_copy);
     d_base = o.d_base;
     first_shard = o.first_shard;
@@ -186,14 +165,19 @@ struct DeviceCtx {
   {
     if (stream) {
       (void)hipSetDevice(device);
+      (void)hipEventDestroy(ev_a);
+      (void)hipEventDestroy(ev_b);
       (void)hipStreamDestroy(stream);
     }
   }
   void activate()
   {
     GGNN_HIP_CHECK(hipSetDevice(device));
-    if (!stream)
+    if (!stream) {
       GGNN_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      GGNN_HIP_CHECK(hipEventCreate(&ev_a));
+      GGNN_HIP_CHECK(hipEventCreate(&ev_b));
+    }
   }
 };
 
@@ -388,7 +372,7 @@ struct ggnn_handle {
       const bool use_ps = ensure_prescreen(ctx, si, measure);
       Shard& sh = ctx.shards[si];
       const void* base = shard_base(ctx, si);
-      EventTimer timer(stream);
+      EventTimer timer(stream, ctx.ev_a, ctx.ev_b);
 
       auto layer_graph = [&](uint32_t l) {
         return sh.graph + static_cast<size_t>(cfg.Ns_offsets[l]) * K;
@@ -650,7 +634,7 @@ struct ggnn_handle {
         ql.ps_Dc = prescreen_code_dim(pad_D);
       }
       ql.n_rows = c_rows.as<uint32_t>();
-      EventTimer timer(stream);
+      EventTimer timer(stream, ctx.ev_a, ctx.ev_b);
       launch_query(ql, stream);
       const float ms = timer.stop();
       ctx.query_ms += ms;
@@ -785,7 +769,7 @@ struct ggnn_handle {
     }
     BfLaunch bl{ctx.d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
                 measure,    d_ids,  d_dists};
-    EventTimer timer(ctx.stream);
+    EventTimer timer(ctx.stream, ctx.ev_a, ctx.ev_b);
     launch_bf_query(bl, ctx.stream);
     bf_ms = timer.stop();
     GGNN_LOG(0, "[GPU: %d] brute-force query: => ms: %.3f [%u points query -> %.3f us/point]",
