@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--tau-build", type=float, default=0.5)
     ap.add_argument("--refine", type=int, default=2)
     ap.add_argument("--tau-query", type=float, default=0.9)
-    ap.add_argument("--max-iters", type=int, default=200)
+    ap.add_argument("--max-iters", type=int, default=175)
     ap.add_argument("--dataset", default="lowrank16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--saturated-batch", action="store_true",
