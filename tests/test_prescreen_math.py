@@ -100,3 +100,46 @@ def test_a_rejected_candidate_is_at_least_as_far_as_the_criteria(name, power_of_
     assert checked > 0
     if name in ("integers", "fractional", "negative"):
         assert rejected > 0.3 * checked / 3  # and the bound is useful, not vacuous
+
+
+def cosine_distance_lower(q, x):
+    """smallest value a float32 evaluation of |1 - q.x / sqrt(|q|^2 |x|^2)| can return"""
+    q64, x64 = q.astype(np.float64), x.astype(np.float64)
+    nn = (q64 * q64).sum() * (x64 * x64).sum()
+    if nn <= 0:
+        return 1.0
+    d = abs(1.0 - (q64 * x64).sum() / np.sqrt(nn))
+    return d - (q.size + 8) * 2.0 ** -24  # absolute: the cancellation in 1 - cos
+
+
+@pytest.mark.parametrize("name", ["fractional", "large offset", "negative", "integers"])
+def test_cosine_variant(name):
+    rng = np.random.default_rng(hash(name) % 997)
+    N, D, Nq = 300, 64, 30
+    base = CASES[name](rng, N, D)
+    base[3] = 0  # zero rows stay zero after "normalisation" and have distance 1 to everything
+    queries = CASES[name](rng, Nq, D)
+    norms = np.sqrt((base.astype(np.float64) ** 2).sum(1))
+    unit = np.where(norms[:, None] > 0, base / np.maximum(norms, 1e-300)[:, None], 0.0)
+    # codes are measured against the exactly normalised rows (prescreen.hip, cosine mode)
+    codes, o, s, inv_s, _, o_norm = encode(unit.astype(F), False)
+    res = unit - (o.astype(np.float64) + np.float64(s) * codes)
+    e_max = F(np.sqrt((res ** 2).sum(1)).max()) * (F(1) + F(1e-6)) + F(1e-12) * (
+        o_norm + F(255) * s * F(np.sqrt(D)))
+    rejected = 0
+    for q in queries:
+        qn = F(np.sqrt((q * q).sum(dtype=F)))
+        qu = (q * (F(1) / qn)).astype(F)
+        cq, slack, m = query_side(qu, o, s, inv_s, e_max, o_norm, D)
+        # Prescreen::load uses |q^| = 1 for the slack of the cosine mode
+        slack = slack - F(8) * U * F(np.sqrt((qu * qu).sum(dtype=F))) + F(8) * U
+        S = ((cq[None, :] - codes) ** 2).sum(1).astype(F)
+        for i in range(N):
+            d_low = cosine_distance_lower(q, base[i])
+            for crit in (F(max(d_low, 0.0)) + F(1e-7), F(max(d_low, 0.0) * 0.5)):
+                c2 = F(2) * (crit + m) * (F(1) + m)
+                if S[i] >= threshold(c2, slack, inv_s, m):
+                    rejected += 1
+                    assert d_low >= float(crit), (name, i)
+    if name != "large offset":  # there all vectors are parallel: distances below the margin
+        assert rejected > 0
