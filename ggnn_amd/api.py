@@ -237,13 +237,20 @@ class GGNN:
         self._check(lib().ggnn_store(self._h))
 
     def _update_shards(self):
-        n_shard = getattr(self, "_n_shard", 0)
-        self._shards = (self._base_shape[0] // n_shard) if n_shard else 1
+        # shards per GPU as laid out by the engine: width factor of results kept on the GPU
+        per_gpu = C.c_uint32(1)
+        self._check(lib().ggnn_get_shard_layout(self._h, None, C.byref(per_gpu), None))
+        self._shards = int(per_gpu.value)
 
     def _out(self, Nq, width, on_gpu, device):
         dev = device if on_gpu else "cpu"
         ids = torch.empty((Nq, width), dtype=torch.int32, device=dev)
         dists = torch.empty((Nq, width), dtype=torch.float32, device=dev)
+        if on_gpu:
+            # the blocks come from torch's caching allocator, which orders their reuse on torch's
+            # stream; the engine writes them on its own stream, so work torch has queued on a
+            # recycled block must have finished before the engine touches it
+            torch.cuda.current_stream(device).synchronize()
         return ids, dists
 
     def _result_device(self, t):

@@ -130,6 +130,18 @@ struct Shard {
 
 using namespace ggnn_amd;
 
+// destroying a DeviceCtx switches devices; leave the caller's current device as it was
+struct DeviceRestoreGuard {
+  int prev{-1};
+  DeviceRestoreGuard() { (void)hipGetDevice(&prev); }
+  ~DeviceRestoreGuard()
+  {
+    int now = -1;
+    if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev)
+      (void)hipSetDevice(prev);
+  }
+};
+
 // everything one GPU owns (GPUInstance of the reference, gpu_instance.cuh:60-221, reduced to
 // resident shards)
 struct DeviceCtx {
@@ -220,9 +232,29 @@ struct ggnn_handle {
 
   size_t row_bytes() const { return static_cast<size_t>(pad_D) * dtype_size(base_dtype); }
   uint32_t num_shards() const { return shards_per_gpu * static_cast<uint32_t>(devs.size()); }
+  // every shard of every GPU is built or loaded (a partly loaded handle has no graph)
   bool has_graph() const
   {
-    return prepared && !devs.empty() && !devs[0].shards.empty() && devs[0].shards[0].ready;
+    if (!prepared || devs.empty())
+      return false;
+    for (const DeviceCtx& ctx : devs) {
+      if (ctx.shards.empty())
+        return false;
+      for (const Shard& sh : ctx.shards)
+        if (!sh.ready)
+          return false;
+    }
+    return true;
+  }
+  // a failed prepare / build / load leaves the handle as it was after set_base: no contexts, no
+  // half-initialised shards, and build()/load()/set_base() may be called again
+  void rollback_graph()
+  {
+    DeviceRestoreGuard keep;
+    devs.clear();
+    prepared = false;
+    shards_per_gpu = 0;
+    cfg = ggnn_graph_config{};
   }
 
   // runs f(ctx) for every GPU -- inline for one GPU, one host thread per GPU otherwise (the
@@ -328,24 +360,30 @@ struct ggnn_handle {
     shards_per_gpu = static_cast<uint32_t>(spg);
     // reuse a context created by an earlier bf_query() when it fits
     const bool reuse = devs.size() == 1 && num_gpus == 1 && devs[0].device == gpus[0];
-    if (!reuse) {
-      devs.clear();
-      devs.resize(num_gpus);
-    }
-    for (uint32_t i = 0; i < num_gpus; ++i) {
-      DeviceCtx& ctx = devs[i];
-      ctx.device = gpus[i];
-      ctx.first_shard = i * shards_per_gpu;
-      ctx.activate();
-      if (!reuse)
-        stage_base_slice(ctx, static_cast<uint64_t>(ctx.first_shard) * n,
-                         static_cast<uint64_t>(shards_per_gpu) * n);
-      ctx.shards.clear();
-      ctx.shards.resize(shards_per_gpu);
-      for (uint32_t s = 0; s < shards_per_gpu; ++s) {
-        ctx.shards[s].global_id = ctx.first_shard + s;
-        ctx.shards[s].allocate(cfg);
+    try {
+      if (!reuse) {
+        devs.clear();
+        devs.resize(num_gpus);
       }
+      for (uint32_t i = 0; i < num_gpus; ++i) {
+        DeviceCtx& ctx = devs[i];
+        ctx.device = gpus[i];
+        ctx.first_shard = i * shards_per_gpu;
+        ctx.activate();
+        if (!reuse)
+          stage_base_slice(ctx, static_cast<uint64_t>(ctx.first_shard) * n,
+                           static_cast<uint64_t>(shards_per_gpu) * n);
+        ctx.shards.clear();
+        ctx.shards.resize(shards_per_gpu);
+        for (uint32_t s = 0; s < shards_per_gpu; ++s) {
+          ctx.shards[s].global_id = ctx.first_shard + s;
+          ctx.shards[s].allocate(cfg);
+        }
+      }
+    }
+    catch (...) {
+      rollback_graph();
+      throw;
     }
     prepared = true;
     GGNN_LOG(1, "prepare: gpus=%zu N_shard=%u shards/gpu=%u D=%u K=%u G=%u S=%u S0=%u S0_off=%u",
@@ -477,8 +515,14 @@ struct ggnn_handle {
              ggnn_measure measure)
   {
     prepare(KBuild);
-    for_each_device(
-        [&](DeviceCtx& ctx) { build_device(ctx, tau_build, refinement_iterations, measure); });
+    try {
+      for_each_device(
+          [&](DeviceCtx& ctx) { build_device(ctx, tau_build, refinement_iterations, measure); });
+    }
+    catch (...) {
+      rollback_graph();
+      throw;
+    }
     build_ms = 0.f;
     for (const DeviceCtx& ctx : devs)
       build_ms += ctx.build_ms;  // "Sum of shard build times", ggnn.cu:237
@@ -814,6 +858,17 @@ struct ggnn_handle {
     if (graph_dir.empty())
       graph_dir = std::filesystem::current_path();
     prepare(KBuild);
+    try {
+      load_shards();
+    }
+    catch (...) {
+      rollback_graph();
+      throw;
+    }
+    release_caller_copy();
+  }
+  void load_shards()
+  {
     for_each_device([&](DeviceCtx& ctx) {
       std::vector<char> host(Shard::pool_bytes(cfg));
       for (Shard& sh : ctx.shards) {
@@ -830,7 +885,6 @@ struct ggnn_handle {
         sh.ready = true;
       }
     });
-    release_caller_copy();
   }
 };
 
@@ -976,7 +1030,24 @@ ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uin
 
 ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable)
 {
-  return guarded(h, [&] { h->prescreen = enable != 0; });
+  GGNN_NEED_HANDLE(h);
+  h->prescreen = enable != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_get_shard_layout(const ggnn_t* h, uint32_t* num_shards, uint32_t* shards_per_gpu,
+                                  uint32_t* n_shard)
+{
+  GGNN_NEED_HANDLE(h);
+  if (!h->has_graph())
+    return GGNN_INVALID_STATE;
+  if (num_shards)
+    *num_shards = h->num_shards();
+  if (shards_per_gpu)
+    *shards_per_gpu = h->shards_per_gpu;
+  if (n_shard)
+    *n_shard = h->cfg.N;
+  return GGNN_OK;
 }
 
 ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable)

@@ -55,8 +55,14 @@ void launch_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, floa
   if (!Nq || row_len <= 1)
     return;
   GGNN_REQUIRE(row_len <= 12000, GGNN_UNSUPPORTED, "result rows longer than 12000 entries");
-  hipLaunchKernelGGL(sort_rows_kernel, grid_for(Nq), dim3(kWave), 3 * row_len * sizeof(int), stream,
-                     Nq, row_len, ids, dists);
+  const size_t lds = 3 * static_cast<size_t>(row_len) * sizeof(int);
+  // more than the default 64 KB of dynamic LDS (KQuery x shards_per_gpu > 5461) has to be asked for
+  if (lds > 64 * 1024)
+    GGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+  hipLaunchKernelGGL(sort_rows_kernel, grid_for(Nq), dim3(kWave), lds, stream, Nq, row_len, ids,
+                     dists);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 

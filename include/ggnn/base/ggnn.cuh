@@ -81,7 +81,6 @@ class GGNN {
   virtual void setShardSize(const uint32_t N_shard)
   {
     detail::check(ggnn_set_shard_size(h_, N_shard), h_);
-    n_shard_ = N_shard;
   }
   virtual void setReturnResultsOnGPU(const bool return_results_on_gpu = true)
   {
@@ -177,11 +176,14 @@ class GGNN {
   void set_base_impl(const GenericDataset& b)
   {
     detail::check(ggnn_set_base(h_, b.raw(), b.N, b.D, dtype_of(b), loc_of(b), b.gpu_id, 0), h_);
-    base_n_ = b.N;
   }
+  // shards per GPU as the engine laid them out (results on the GPU are [Nq, KQuery * shards],
+  // ggnn.cu:299-306); asked from the engine so that nothing is cached in this movable object
   uint32_t num_shards() const
   {
-    return n_shard_ ? static_cast<uint32_t>(base_n_ / n_shard_) : 1u;
+    uint32_t per_gpu = 1;
+    detail::check(ggnn_get_shard_layout(h_, nullptr, &per_gpu, nullptr), h_);
+    return per_gpu;
   }
   Results make_results(const GenericDataset& query, uint32_t width)
   {
@@ -200,8 +202,6 @@ class GGNN {
   ggnn_t* h_{nullptr};
   GenericDataset owned_base_{};
   Graph graph_view_{};
-  uint64_t base_n_{0};
-  uint32_t n_shard_{0};
   bool on_gpu_{false};
 };
 

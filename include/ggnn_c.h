@@ -136,6 +136,11 @@ ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uin
  * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
  * environment variable GGNN_PRESCREEN=0 turns the default off. */
 ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable);
+/* shard layout chosen by ggnn_build / ggnn_load (GGNNImpl::prepare, ggnn.cu:154-203): total
+ * number of shards, shards per GPU (the width factor of results returned on the GPU,
+ * ggnn.cu:299-306) and points per shard.  GGNN_INVALID_STATE without a graph. */
+ggnn_status ggnn_get_shard_layout(const ggnn_t* h, uint32_t* num_shards, uint32_t* shards_per_gpu,
+                                  uint32_t* n_shard);
 /* nanobind.cu:151 set_log_level */
 void ggnn_set_log_level(int level);
 

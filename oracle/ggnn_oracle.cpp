@@ -1442,3 +1442,18 @@ void orc_wave_model_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, float
 }
 
 }  // extern "C"
+
+extern "C" {
+uint32_t orc_bit_ceil(uint32_t v)
+{
+  return bit_ceil_u32(v);
+}
+uint32_t orc_next_multiple32(uint32_t v)
+{
+  return next_multiple32(v);
+}
+size_t orc_align8(size_t v)
+{
+  return ((v + 7) / 8) * 8;  // include/ggnn/base/def.h:64-68
+}
+}

@@ -38,6 +38,11 @@ struct OrcGraphConfig {
 };
 void orc_graph_config(uint32_t N, uint32_t D, uint32_t KBuild, OrcGraphConfig* out);
 
+// include/ggnn/base/def.h:37-68 (the helpers every sizing rule is built on)
+uint32_t orc_bit_ceil(uint32_t v);
+uint32_t orc_next_multiple32(uint32_t v);
+size_t orc_align8(size_t v);
+
 // host sizing rules, src/ggnn/query/query_kernels.cu:55-110
 struct OrcQuerySizing {
   uint32_t cache_size, sorted_size, block_dim_x;

@@ -300,6 +300,25 @@ def kbest_script(BEST, BLOCK, dists, ids, check_worst=True):
 
 
 REF_KBEST_SO = os.path.join(_HERE, "_ref", "libggnn_ref_kbest.so")
+REF_DEF_SO = os.path.join(_HERE, "_ref", "libggnn_ref_def.so")
+
+
+def bit_ceil(v):
+    f = lib().orc_bit_ceil
+    f.restype = C.c_uint32
+    return int(f(C.c_uint32(v)))
+
+
+def next_multiple32(v):
+    f = lib().orc_next_multiple32
+    f.restype = C.c_uint32
+    return int(f(C.c_uint32(v)))
+
+
+def align8(v):
+    f = lib().orc_align8
+    f.restype = C.c_size_t
+    return int(f(C.c_size_t(v)))
 
 
 def cache_script(BEST, SORTED, CACHE, BLOCK, xi, ops):

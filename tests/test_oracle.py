@@ -41,6 +41,30 @@ def test_query_sizing_appendix_b(orc):
         assert (s.cache_size, s.sorted_size, s.block_dim_x) == (cache, sorted_, block)
 
 
+def test_sizing_helpers_pinned_to_reference_def_h(orc):
+    """oracle/_ref/libggnn_ref_def.so is the reference's own include/ggnn/base/def.h compiled
+    unchanged with g++ (oracle/ref_def_harness.cpp): bit_ceil / next_multiple<32> / align8 of the
+    oracle -- and through test_cabi.py::test_query_sizing_matches_oracle of the engine -- must
+    agree with it on every value the sizing rules can see (query_kernels.cu:55-110: KQuery <= 6000,
+    max_iterations <= 8192, D <= 4096)."""
+    import ctypes as C
+    if not os.path.exists(orc.REF_DEF_SO):
+        pytest.skip("oracle/_ref was not built (reference tree not mounted at build time)")
+    ref = C.CDLL(orc.REF_DEF_SO)
+    ref.ref_bit_ceil.restype = C.c_uint32
+    ref.ref_next_multiple32.restype = C.c_uint32
+    ref.ref_align8.restype = C.c_size_t
+    ref.ref_align8.argtypes = [C.c_size_t]
+    values = list(range(0, 8300)) + [2 ** k + o for k in range(13, 32) for o in (-1, 0, 1)
+                                     if 0 <= 2 ** k + o < 2 ** 31 + 1]
+    for v in values:
+        assert orc.bit_ceil(v) == ref.ref_bit_ceil(C.c_uint32(v)), v
+        assert orc.next_multiple32(v) == ref.ref_next_multiple32(C.c_uint32(v)), v
+    for v in list(range(0, 100)) + [2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 125_793_824 * 24 * 4 + 13]:
+        assert orc.align8(v) == ref.ref_align8(v), v
+    assert (ref.ref_measure_euclidean(), ref.ref_measure_cosine()) == (orc.EUCLIDEAN, orc.COSINE)
+
+
 # ---- KBestList / cache known-answer tests ----------------------------------------------------
 def test_kat_q1_ring_wrap_loss(orc):
     """SURVEY.md Q1, derived from simple_knn_cache.cuh:167-172: BEST=2, SORTED=6, head=4,
