@@ -95,6 +95,9 @@ SIGNATURES = {
                                          _vp, _u32, _f32, _u32, _int, _u32, _u32, _vp, _vp, _vp,
                                          _vp, _vp, _vp]),
     "ggnn_op_bf_query": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp, _vp]),
+    "ggnn_op_bf_query_certified": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp,
+                                          _vp, _vp]),
+    "ggnn_last_bf_query_rescanned": (_int, [_vp, C.POINTER(_u32)]),
     "ggnn_op_top": (_int, [_vp, _int, _u32, _int, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp,
                            _vp]),
     "ggnn_op_merge": (_int, [_vp, _int, _int, _cfgp, _vp, _vp, _vp, _vp, _f32, _u32, _u32, _vp,

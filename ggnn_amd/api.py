@@ -337,6 +337,13 @@ class GGNN:
         extension: same results, less memory traffic; costs N x D bytes per shard)."""
         self._check(lib().ggnn_set_prescreen(self._h, int(bool(enable))))
 
+    def last_bf_query_rescanned(self):
+        """queries of the last bf_query answered by the exhaustive scan because the matrix-core
+        pre-selection could not be certified exact (results are exact either way)"""
+        n = C.c_uint32()
+        self._check(lib().ggnn_last_bf_query_rescanned(self._h, C.byref(n)))
+        return int(n.value)
+
     def last_query_counters(self):
         d, p = C.c_uint64(), C.c_uint64()
         self._check(lib().ggnn_last_query_counters(self._h, C.byref(d), C.byref(p)))

@@ -14,8 +14,26 @@
 //   3. bf_rerank_kernel: the candidates of all base slices are re-evaluated with the reference's
 //      direct formula (DistEngine, distance.cuh:119-163) and ranked by (distance, index), so the
 //      returned distances are the direct-form values; the expanded form only pre-selects.
-//      On integer-valued data (<= 2^24) both forms are exact and the result is bit-identical to
-//      the scan kernel and to the oracle.
+//   4. Exactness certificate (per query, in the re-rank kernel) and exact fallback: see
+//      "Why the pre-selection cannot lose a neighbour" below.  Queries that cannot be certified
+//      are answered by the scan kernel (bf_query.hip), so the result is ALWAYS the top K by
+//      (direct-form distance, index) -- the reference's result (bf_query_layer.cu:52-57).
+//
+// Why the pre-selection cannot lose a neighbour
+//   Float32 squared L2 works on a = fl(q - mu), b = fl(x - mu) with mu = a column mean of the
+//   base (any vector works: L2 is shift invariant; centring makes the norms comparable to the
+//   distances, so the expanded form does not cancel).  With u = 2^-24, for ANY summation order
+//     |d_e - ||a-b||^2|  <= (2D+4) u (|a|^2+|b|^2)      (two norm chains, dot chain, 2 roundings)
+//     | ||a-b||^2 - ||q-x||^2 | <= 4u (|a|^2+|b|^2)     (rounding of the centred coordinates)
+//     d_dir >= ||q-x||^2 (1 - (D+3)u)                   (direct form: diff, fma chain, tree)
+//   A slice list keeps the KP smallest (d_e, index); a row left out of the list of slice s has
+//   d_e >= w_s (the list's worst entry, +inf while the list is not full).  Hence with
+//     E = 1.01 (2D+8) u (|a|^2 + max_rows |b|^2) + 4u w      and      w = min_s w_s
+//   every left-out row has d_dir >= (w - E)(1 - 1.01 (D+3) u).  If that exceeds the K-th re-ranked
+//   distance the query is certified; otherwise it is re-scanned.  Cosine: both forms are within
+//   (2D+8)u of the true |1 - cos| in absolute terms (|cos| <= 1), so E = 2.02 (2D+8) u.
+//   uint8 rows on the i8 path: every quantity is an exact integer < 2^24, a left-out row is
+//   preceded by KP > K rows of its own slice in exact (distance, index) order: nothing to check.
 #include <cstdlib>
 
 #include "traversal.hpp"
@@ -31,6 +49,7 @@ constexpr uint32_t kBfMaxKP = 120;  // lists of 128 queries must fit into LDS ne
 struct BfMfmaArgs {
   const void* base;
   const void* query;
+  const float* mean;   // [D] shift applied to base and query rows (float32 squared L2), or null
   const float* bnorm;
   const float* qnorm;
   int32_t* part_ids;   // [slices][Nq][KP]
@@ -41,9 +60,13 @@ struct BfMfmaArgs {
 // ---- 1. squared norms ---------------------------------------------------------------------------
 // SHIFT (uint8 only): norms of x - 128, the values the i8 matrix path works on; squared L2
 // distances do not change under a common shift
+// mean (optional): per-column shift, the same fl(x - mean) the tile kernel forms
+// max_out (optional): running maximum of the norms as float bits (norms are >= 0, so the
+// unsigned order of the bit patterns is the numeric order)
 template <typename BaseT, bool SHIFT = false>
 __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint32_t N, uint32_t D,
-                                                       float* out)
+                                                       const float* mean, float* out,
+                                                       uint32_t* max_out)
 {
   constexpr int EPC = ChunkOf<BaseT>::EPC;
   using Chunk = typename ChunkOf<BaseT>::type;
@@ -56,14 +79,47 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
       const Chunk v = *reinterpret_cast<const Chunk*>(p + e0);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const float x = ChunkOf<BaseT>::get(v, e) - (SHIFT ? 128.f : 0.f);
+        const float x = ChunkOf<BaseT>::get(v, e) - (SHIFT ? 128.f : (mean ? mean[e0 + e] : 0.f));
         acc = fmaf(x, x, acc);
       }
     }
   }
   acc = group_sum<16>(acc);
-  if (row < N && g == 0)
+  if (row < N && g == 0) {
     out[row] = acc;
+    if (max_out)
+      atomicMax(max_out, __float_as_uint(acc));
+  }
+}
+
+// Column means of (a sample of) the base: partial[p][c] = sum over rows p, p+P, ... of the
+// sampled rows; finalised in a fixed order, so the shift -- and with it every intermediate of the
+// tile kernel -- is the same from run to run.  The shift only has to be close to the data: any
+// vector gives exact results (see the certificate above).
+constexpr uint32_t kBfMeanBlocks = 256;
+__global__ void __launch_bounds__(256) col_mean_partial_kernel(const float* data, uint32_t N,
+                                                              uint32_t D, uint32_t stride,
+                                                              uint32_t rows, float* partial)
+{
+  for (uint32_t c = threadIdx.x; c < D; c += 256) {
+    float acc = 0.f;
+    for (uint32_t r = blockIdx.x; r < rows; r += kBfMeanBlocks)
+      acc += data[static_cast<size_t>(r) * stride * D + c];
+    partial[blockIdx.x * D + c] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) col_mean_final_kernel(const float* partial, uint32_t D,
+                                                            uint32_t rows, float* mean)
+{
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D)
+    return;
+  float acc = 0.f;
+  for (uint32_t p = 0; p < kBfMeanBlocks; ++p)
+    acc += partial[p * D + c];
+  const float m = acc / static_cast<float>(rows);
+  // data the mean of which is not finite is left unshifted (the certificate then decides)
+  mean[c] = (fabsf(m) < inf_f()) ? m : 0.f;
 }
 
 // ---- 2. tile kernel -------------------------------------------------------------------------------
@@ -78,7 +134,20 @@ struct TileStage;
 template <>
 struct TileStage<float> {
   float4 r[4];
+  float4 mu[4];  // shift of this thread's columns (zero without centring)
   float bn;  // threads 0..31: squared norm of tile row threadIdx.x (pad value past the end)
+  // columns [col0, col0 + CW) are staged next; the single-chunk kernel calls this once
+  GGNN_DEV void set_mean(const float* mean, uint32_t D, uint32_t col0, uint32_t CW)
+  {
+    const uint32_t cpr = CW / 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t col = col0 + 4 * ((threadIdx.x + 256 * e) % cpr);
+      mu[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mean && col < D)
+        mu[e] = *reinterpret_cast<const float4*>(mean + col);
+    }
+  }
   GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
                      uint32_t CW, const float* bnorm, float bn_pad)
   {
@@ -90,7 +159,7 @@ struct TileStage<float> {
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, col = col0 + 4 * (idx % cpr);
-      r[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      r[e] = mu[e];  // rows / columns past the end stage as zero after the shift
       if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D)
         r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + col);
     }
@@ -105,7 +174,8 @@ struct TileStage<float> {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, c4 = idx % cpr;
       if (row < (uint32_t)kBfTileRows)
-        *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) = r[e];
+        *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) =
+            make_float4(r[e].x - mu[e].x, r[e].y - mu[e].y, r[e].z - mu[e].z, r[e].w - mu[e].w);
     }
   }
 };
@@ -115,6 +185,7 @@ template <>
 struct TileStage<uint8_t> {
   uint4 r;
   float bn;
+  GGNN_DEV void set_mean(const float*, uint32_t, uint32_t, uint32_t) {}  // bytes are not shifted
   GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
                      uint32_t CW, const float* bnorm, float bn_pad)
   {
@@ -150,13 +221,18 @@ struct TileStage<uint8_t> {
 
 // A operand of one chunk: aq[kk] = q[col0 + h*Dh + kk] (0 outside the row / the query set)
 GGNN_DEV void load_query_chunk(float (&aq)[64], const float* qrow, bool qvalid, uint32_t D,
-                               uint32_t Dh, uint32_t col_h)
+                               uint32_t Dh, uint32_t col_h, const float* mean)
 {
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qvalid && static_cast<uint32_t>(4 * t) < Dh && col_h + 4 * t < D)
+    if (qvalid && static_cast<uint32_t>(4 * t) < Dh && col_h + 4 * t < D) {
       v = *reinterpret_cast<const float4*>(qrow + col_h + 4 * t);
+      if (mean) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + col_h + 4 * t);
+        v = make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w);
+      }
+    }
     aq[4 * t + 0] = v.x;
     aq[4 * t + 1] = v.y;
     aq[4 * t + 2] = v.z;
@@ -164,7 +240,7 @@ GGNN_DEV void load_query_chunk(float (&aq)[64], const float* qrow, bool qvalid, 
   }
 }
 GGNN_DEV void load_query_chunk(float (&aq)[64], const uint8_t* qrow, bool qvalid, uint32_t D,
-                               uint32_t Dh, uint32_t col_h)
+                               uint32_t Dh, uint32_t col_h, const float*)
 {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -298,6 +374,7 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
   // squared norm standing in for rows past the end of the slice: +inf distance for L2
   const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
   TileStage<BaseT> stage;
+  stage.set_mean(a.mean, a.D, 0, CW);
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
     stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
@@ -310,7 +387,7 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
     // of tile t -- its 16 x (add, fma, compare) are independent of the running accumulator, so
     // the matrix pipe does not drain between tiles.  Before the first tile the "previous"
     // accumulator is a dummy whose distances are +inf.
-    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
+    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh, a.mean);
     f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bn_prev = bn_pad;
     bool jvalid_prev = false;
@@ -378,7 +455,7 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
 
     for (uint32_t c = 0; c < nch; ++c) {
       if (nch > 1 || g0 == 0)
-        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, c * CW + h * a.Dh);
+        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, c * CW + h * a.Dh, a.mean);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t tt = g0 + t;
@@ -399,9 +476,12 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           else
             has_next = false;
         }
-        if (has_next)
+        if (has_next) {
+          if (nch > 1)
+            stage.set_mean(a.mean, a.D, n_chunk * CW, CW);
           stage.load(base, a.D, begin + n_tile * kBfTileRows, end, n_chunk * CW, CW, a.bnorm,
                      bn_pad);
+        }
 
         // S += Q_chunk x B_chunk^T for this wave's 32 queries against the 32 tile rows
         const float* bt = lds_f + (p & 1) * tile_floats + j * a.DP + h * a.Dh;
@@ -614,9 +694,15 @@ struct BfRerankArgs {
   const void* base;
   const void* query;
   const int32_t* part_ids;
+  const float* part_dists;   // expanded-form distances of the candidates (certificate)
+  const float* qnorm;        // squared norms the tile kernel used (shifted rows)
+  const uint32_t* bnorm_max; // float bits of the largest base-row norm
+  uint32_t* rescan_count;    // queries that could not be certified ...
+  uint32_t* rescan_list;     // ... and their indices (answered by the scan kernel afterwards)
   int32_t* ids;
   float* dists;
   uint32_t D, Nq, K, KP, slices, cap;
+  int exact_arith;           // i8 path: integer arithmetic, nothing to certify
 };
 
 template <typename BaseT, int LPR, int NCH, int MODE>
@@ -672,11 +758,42 @@ __global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
       out_i[rank] = id;
       out_d[rank] = d;
     }
+    if (rank + 1 == a.K)
+      lds.cd0[0] = d;  // K-th distance, for the certificate below
   }
   for (uint32_t k = count + lane; k < a.K; k += kWave) {
     out_i[k] = kEmptyKey;
     out_d[k] = inf_f();
   }
+
+  // ---- certificate (see the top of this file) -------------------------------------------------
+  if (a.exact_arith || count < a.K)
+    return;  // exact integers, or every row of the base is a candidate
+  // w: smallest "worst kept" expanded-form distance over the slices (+inf: list not full)
+  float w = inf_f();
+  for (uint32_t s = lane; s < a.slices; s += kWave)
+    w = fminf(w, a.part_dists[(static_cast<size_t>(s) * a.Nq + n) * a.KP + a.KP - 1]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1)
+    w = fminf(w, __shfl_xor(w, o));
+  __syncthreads();  // the K-th distance was left in LDS by the lane that ranked it
+  const float d_k = lds.cd0[0];
+  constexpr float u = 5.9604645e-8f;  // 2^-24
+  const float Df = static_cast<float>(a.D);
+  bool ok;
+  if (MODE == kL2) {
+    const float norms = a.qnorm[n] + __uint_as_float(*a.bnorm_max);
+    const float E = 1.01f * (2.f * Df + 8.f) * u * norms + 4.f * u * w;
+    ok = (w - E) * (1.f - 1.01f * (Df + 3.f) * u) > d_k;
+  }
+  else {
+    const float E = 2.02f * (2.f * Df + 8.f) * u;
+    ok = w - E > d_k;
+  }
+  if (!(w < inf_f()))
+    ok = true;  // no list is full: nothing was left out
+  if (!ok && lane == 0)
+    a.rescan_list[atomicAdd(a.rescan_count, 1u)] = n;
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -686,17 +803,41 @@ bool bf_mfma_supported(const BfLaunch& a)
   return a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 && a.N_base >= 4096;
 }
 
+// freed blocks stay in the device's pool instead of going back to the driver at the next
+// synchronisation: the per-call scratch of bf_query then costs no allocation after the first call
+static void keep_pool_memory(hipStream_t)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+    return;
+  static bool done[64] = {};
+  if (done[dev])
+    return;
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+    uint64_t keep = ~0ull;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
+  (void)hipGetLastError();
+  done[dev] = true;
+}
+
+size_t bf_rescan_tmp_entries(const BfLaunch& a, uint32_t* slices_out);
+void launch_bf_rescan(const BfLaunch& a, const uint32_t* qlist, const uint32_t* qcount,
+                      int32_t* tmp_ids, float* tmp_dists, hipStream_t stream);
+
 void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
 {
   check_vector_layout(a.base, a.D, a.dtype);
   check_vector_layout(a.query, a.D, a.dtype);
-  const uint32_t KP = a.k_query + 8;  // margin against rounding of the expanded distance form
-  const uint32_t vec = a.dtype == GGNN_F32 ? 4 : 16;
+  keep_pool_memory(stream);
+  // a few more candidates than K per slice: makes the certificate (top of this file) succeed for
+  // all but near-degenerate queries; correctness does not depend on the value
+  const uint32_t KP = a.k_query + 8;
   // one chunk of 2*Dh columns when the row fits (D <= 128), otherwise chunks of 128 columns
   // half-row width: 64 when D > 128 (K streams in chunks), otherwise 32 / 48 / 64 so that the
   // single chunk covers the row (columns past D are zero in the tile and in the query operand)
   const uint32_t Dh = a.D > 128 ? 64 : (a.D <= 64 ? 32 : a.D <= 96 ? 48 : 64);
-  (void)vec;
   const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
   const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
   // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
@@ -709,20 +850,53 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
 
-  float* norms = nullptr;
-  int32_t* part_ids = nullptr;
-  float* part_dists = nullptr;
+  // uint8 + squared L2 with rows of up to 128 bytes: integer contraction (bf_mfma_i8_kernel)
+  const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
+                      std::getenv("GGNN_BF_NO_I8") == nullptr;
+  // float32 squared L2: rows are shifted by a column mean of the base (GGNN_BF_NO_CENTER=1: test
+  // hook that leaves them unshifted so that offset data exercises the re-scan)
+  const bool center = a.dtype == GGNN_F32 && a.measure == GGNN_EUCLIDEAN &&
+                      std::getenv("GGNN_BF_NO_CENTER") == nullptr;
+
+  // one scratch block: [norms N+Nq][mean D][mean partials 256 D][bn_max, rescan_count]
+  // [rescan_list Nq][part ids][part dists][re-scan slices ids][re-scan slices dists]
   const size_t parts = static_cast<size_t>(slices) * a.Nq * KP;
-  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&norms),
-                                (static_cast<size_t>(a.N_base) + a.Nq) * 4, stream));
-  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part_ids), parts * 4, stream));
-  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&part_dists), parts * 4, stream));
-  float* bnorm = norms;
-  float* qnorm = norms + a.N_base;
+  uint32_t rescan_slices = 0;
+  const size_t rescan_entries = use_i8 ? 0 : bf_rescan_tmp_entries(a, &rescan_slices);
+  const size_t n_norms = (static_cast<size_t>(a.N_base) + a.Nq + 3) / 4 * 4;
+  const size_t n_mean = (static_cast<size_t>(a.D) + 3) / 4 * 4;
+  const size_t n_partial = center ? static_cast<size_t>(kBfMeanBlocks) * n_mean : 0;
+  const size_t n_list = (static_cast<size_t>(a.Nq) + 3) / 4 * 4;
+  const size_t words = n_norms + n_mean + n_partial + 4 + n_list + 2 * parts + 2 * rescan_entries;
+  float* scratch = nullptr;
+  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), words * 4, stream));
+  float* bnorm = scratch;
+  float* qnorm = bnorm + a.N_base;
+  float* mean = scratch + n_norms;
+  float* partial = mean + n_mean;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(partial + n_partial);  // [0] bn_max [1] count
+  uint32_t* rescan_list = flags + 4;
+  int32_t* part_ids = reinterpret_cast<int32_t*>(rescan_list + n_list);
+  float* part_dists = reinterpret_cast<float*>(part_ids + parts);
+  int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + parts);
+  float* rescan_dists = reinterpret_cast<float*>(rescan_ids + rescan_entries);
+  GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
+
+  if (center) {
+    // at most ~128k evenly spaced rows: enough for a shift, cheap next to the scan itself
+    const uint32_t stride = std::max(1u, a.N_base / 65536u);
+    const uint32_t rows = (a.N_base + stride - 1) / stride;
+    hipLaunchKernelGGL(col_mean_partial_kernel, dim3(kBfMeanBlocks), dim3(256), 0, stream,
+                       static_cast<const float*>(a.base), a.N_base, a.D, stride, rows, partial);
+    hipLaunchKernelGGL(col_mean_final_kernel, dim3((a.D + 255) / 256), dim3(256), 0, stream, partial,
+                       a.D, rows, mean);
+  }
+  const float* d_mean = center ? mean : nullptr;
 
   BfMfmaArgs m{};
   m.base = a.base;
   m.query = a.query;
+  m.mean = d_mean;
   m.bnorm = bnorm;
   m.qnorm = qnorm;
   m.part_ids = part_ids;
@@ -742,6 +916,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   rr.base = a.base;
   rr.query = a.query;
   rr.part_ids = part_ids;
+  rr.part_dists = part_dists;
+  rr.qnorm = qnorm;
+  rr.bnorm_max = flags;
+  rr.rescan_count = flags + 1;
+  rr.rescan_list = rescan_list;
   rr.ids = a.ids;
   rr.dists = a.dists;
   rr.D = a.D;
@@ -750,14 +929,16 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   rr.KP = KP;
   rr.slices = slices;
   rr.cap = (slices * KP + 3) / 4 * 4;
+  rr.exact_arith = use_i8 ? 1 : 0;
   const size_t rr_lds = wave_lds_bytes(2 * rr.cap);
 
 #define GGNN_BF_MFMA(T, MODE_)                                                                    \
   do {                                                                                            \
     hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,   \
-                       static_cast<const T*>(a.base), a.N_base, a.D, bnorm);                      \
+                       static_cast<const T*>(a.base), a.N_base, a.D, d_mean, bnorm, flags);       \
     hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,       \
-                       static_cast<const T*>(a.query), a.Nq, a.D, qnorm);                         \
+                       static_cast<const T*>(a.query), a.Nq, a.D, d_mean, qnorm,                  \
+                       static_cast<uint32_t*>(nullptr));                                          \
     const void* kern = (a.D > 128) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>)   \
                        : (Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8>)  \
                        : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12>) \
@@ -768,16 +949,15 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     void* kargs[] = {&m};                                                                         \
     GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds, stream));  \
   } while (0)
-  // uint8 + squared L2 with rows of up to 128 bytes: integer contraction (bf_mfma_i8_kernel)
-  const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
-                      std::getenv("GGNN_BF_NO_I8") == nullptr;
   if (use_i8) {
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
                        grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(a.base), a.N_base, a.D, bnorm);
+                       static_cast<const uint8_t*>(a.base), a.N_base, a.D,
+                       static_cast<const float*>(nullptr), bnorm, flags);
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
                        grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,
-                       static_cast<const uint8_t*>(a.query), a.Nq, a.D, qnorm);
+                       static_cast<const uint8_t*>(a.query), a.Nq, a.D,
+                       static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr));
     const size_t lds8 = 2 * kBfI8Tiles * kBfTileRows * kBfI8RowStride +
                         2 * kBfQueriesPerBlock * KP * sizeof(float);
     const uint32_t nm = (a.D + 31) / 32;
@@ -817,9 +997,13 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_BF_RERANK);
 #undef GGNN_BF_RERANK
   GGNN_HIP_CHECK(hipGetLastError());
-  GGNN_HIP_CHECK(hipFreeAsync(norms, stream));
-  GGNN_HIP_CHECK(hipFreeAsync(part_ids, stream));
-  GGNN_HIP_CHECK(hipFreeAsync(part_dists, stream));
+  // queries without a certificate: exact scan (usually none; the surplus blocks leave at once)
+  if (!use_i8)
+    launch_bf_rescan(a, rescan_list, flags + 1, rescan_ids, rescan_dists, stream);
+  if (a.n_rescanned)
+    GGNN_HIP_CHECK(hipMemcpyAsync(a.n_rescanned, flags + 1, sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, stream));
+  GGNN_HIP_CHECK(hipFreeAsync(scratch, stream));
 }
 
 }  // namespace ggnn_amd

@@ -19,6 +19,10 @@ struct BfArgs {
   int32_t* ids;    // [slices x Nq x K] partial results (or final when slices == 1)
   float* dists;
   uint32_t D, Nq, N_base, K, slices, rows_per_slice;
+  // optional subset: only the queries qlist[0, *qcount) are scanned (device memory; the grid is
+  // sized for all Nq queries and the surplus blocks leave at once)
+  const uint32_t* qlist;
+  const uint32_t* qcount;
 };
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE>
@@ -34,8 +38,13 @@ __global__ void __launch_bounds__(kWave) bf_query_kernel(const BfArgs a)
   const uint32_t bid = block_linear_index();
   if (bid >= a.Nq * a.slices)
     return;
-  const uint32_t n = bid / a.slices;
+  uint32_t n = bid / a.slices;
   const uint32_t slice = bid % a.slices;
+  if (a.qlist) {
+    if (n >= *a.qcount)
+      return;
+    n = a.qlist[n];
+  }
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
 
@@ -122,8 +131,13 @@ __global__ void __launch_bounds__(kWave) bf_query_lds_kernel(const BfArgs a)
   const uint32_t bid = block_linear_index();
   if (bid >= a.Nq * a.slices)
     return;
-  const uint32_t n = bid / a.slices;
+  uint32_t n = bid / a.slices;
   const uint32_t slice = bid % a.slices;
+  if (a.qlist) {
+    if (n >= *a.qcount)
+      return;
+    n = a.qlist[n];
+  }
   const BaseT* base = static_cast<const BaseT*>(a.base);
   DE de;
   de.template load_query<MODE>(base, a.D, static_cast<const BaseT*>(a.query) + static_cast<size_t>(n) * a.D);
@@ -219,8 +233,77 @@ static void launch_bf_r(const BfArgs& args, hipStream_t stream)
 bool bf_mfma_supported(const BfLaunch& a);
 void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream);
 
+// scan of all queries (qlist == nullptr) or of the subset qlist[0, *qcount); slices > 1 needs
+// tmp_ids / tmp_dists of [slices x Nq x K] entries
+static void launch_bf_scan(const BfLaunch& a, uint32_t slices, uint32_t rows_per_slice,
+                           const uint32_t* qlist, const uint32_t* qcount, int32_t* tmp_ids,
+                           float* tmp_dists, hipStream_t stream)
+{
+  BfArgs args{};
+  args.base = a.base;
+  args.query = a.query;
+  args.D = a.D;
+  args.Nq = a.Nq;
+  args.N_base = a.N_base;
+  args.K = a.k_query;
+  args.slices = slices;
+  args.rows_per_slice = rows_per_slice;
+  args.qlist = qlist;
+  args.qcount = qcount;
+  args.ids = slices > 1 ? tmp_ids : a.ids;
+  args.dists = slices > 1 ? tmp_dists : a.dists;
+
+#define GGNN_LAUNCH_BF(T, LPR, NCH)                         \
+  do {                                                      \
+    if (a.measure == GGNN_EUCLIDEAN)                        \
+      launch_bf_r<T, LPR, NCH, kL2>(args, stream);          \
+    else                                                    \
+      launch_bf_r<T, LPR, NCH, kCos>(args, stream);         \
+  } while (0)
+  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_BF);
+#undef GGNN_LAUNCH_BF
+  GGNN_HIP_CHECK(hipGetLastError());
+  if (slices > 1)
+    // slices are in ascending base order, so "lower part first" on ties keeps Q2
+    launch_merge_results_subset(a.Nq, a.k_query, slices, a.k_query, 0, tmp_ids, tmp_dists, a.ids,
+                                a.dists, qlist, qcount, stream);
+}
+
+static void slice_rows(uint32_t N_base, uint32_t& slices, uint32_t& rows_per_slice)
+{
+  const uint32_t row_quant = 64;  // multiple of ROWS*STEPS for every configuration
+  slices = std::max(1u, std::min(slices, 64u));
+  rows_per_slice = (N_base + slices - 1) / slices;
+  rows_per_slice = (rows_per_slice + row_quant - 1) / row_quant * row_quant;
+  slices = std::max(1u, (N_base + rows_per_slice - 1) / rows_per_slice);
+}
+
+// exact answers for the queries the MFMA path could not certify (bf_mfma.hip): the scan kernel
+// over qlist[0, *qcount), results written to the rows of those queries in a.ids / a.dists
+size_t bf_rescan_tmp_entries(const BfLaunch& a, uint32_t* slices_out)
+{
+  // few queries are expected: split the base so that even a handful of them keep the chip busy,
+  // within a bounded scratch size (slices x Nq x K entries)
+  uint32_t slices = std::min(32u, std::max(1u, 32768u / std::max(1u, a.Nq)));
+  slices = std::min(slices, std::max(1u, a.N_base / 4096u));
+  uint32_t rows = 0;
+  slice_rows(a.N_base, slices, rows);
+  *slices_out = slices;
+  return slices > 1 ? static_cast<size_t>(slices) * a.Nq * a.k_query : 0;
+}
+void launch_bf_rescan(const BfLaunch& a, const uint32_t* qlist, const uint32_t* qcount,
+                      int32_t* tmp_ids, float* tmp_dists, hipStream_t stream)
+{
+  uint32_t slices = 0, rows = 0;
+  (void)bf_rescan_tmp_entries(a, &slices);
+  slice_rows(a.N_base, slices, rows);
+  launch_bf_scan(a, slices, rows, qlist, qcount, tmp_ids, tmp_dists, stream);
+}
+
 void launch_bf_query(const BfLaunch& a, hipStream_t stream)
 {
+  if (a.n_rescanned)
+    GGNN_HIP_CHECK(hipMemsetAsync(a.n_rescanned, 0, sizeof(uint32_t), stream));
   if (a.Nq == 0)
     return;
   // large batches: Q x B^T on the matrix cores (bf_mfma.hip); GGNN_BF_SCAN=1 forces the scan
@@ -242,22 +325,8 @@ void launch_bf_query(const BfLaunch& a, hipStream_t stream)
   const uint32_t target_waves = 256 * 16;
   if (a.Nq < target_waves)
     slices = std::min((target_waves + a.Nq - 1) / a.Nq, std::max(1u, a.N_base / 4096u));
-  slices = std::max(1u, std::min(slices, 64u));
-  const uint32_t row_quant = 64;  // multiple of ROWS*STEPS for every configuration
-  uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
-  rows_per_slice = (rows_per_slice + row_quant - 1) / row_quant * row_quant;
-  slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
-  slices = std::max(1u, slices);
-
-  BfArgs args{};
-  args.base = a.base;
-  args.query = a.query;
-  args.D = a.D;
-  args.Nq = a.Nq;
-  args.N_base = a.N_base;
-  args.K = a.k_query;
-  args.slices = slices;
-  args.rows_per_slice = rows_per_slice;
+  uint32_t rows_per_slice = 0;
+  slice_rows(a.N_base, slices, rows_per_slice);
 
   int32_t* tmp_ids = nullptr;
   float* tmp_dists = nullptr;
@@ -265,29 +334,9 @@ void launch_bf_query(const BfLaunch& a, hipStream_t stream)
     const size_t n = static_cast<size_t>(a.Nq) * slices * a.k_query;
     GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_ids), n * sizeof(int32_t), stream));
     GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_dists), n * sizeof(float), stream));
-    args.ids = tmp_ids;
-    args.dists = tmp_dists;
   }
-  else {
-    args.ids = a.ids;
-    args.dists = a.dists;
-  }
-
-#define GGNN_LAUNCH_BF(T, LPR, NCH)                         \
-  do {                                                      \
-    if (a.measure == GGNN_EUCLIDEAN)                        \
-      launch_bf_r<T, LPR, NCH, kL2>(args, stream);          \
-    else                                                    \
-      launch_bf_r<T, LPR, NCH, kCos>(args, stream);         \
-  } while (0)
-  GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_BF);
-#undef GGNN_LAUNCH_BF
-  GGNN_HIP_CHECK(hipGetLastError());
-
+  launch_bf_scan(a, slices, rows_per_slice, nullptr, nullptr, tmp_ids, tmp_dists, stream);
   if (slices > 1) {
-    // slices are in ascending base order, so "lower part first" on ties keeps Q2
-    launch_merge_results(a.Nq, a.k_query, slices, a.k_query, 0, tmp_ids, tmp_dists, a.ids,
-                         a.dists, stream);
     GGNN_HIP_CHECK(hipFreeAsync(tmp_ids, stream));
     GGNN_HIP_CHECK(hipFreeAsync(tmp_dists, stream));
   }

@@ -136,6 +136,9 @@ struct BfLaunch {
   ggnn_measure measure;
   int32_t* ids;
   float* dists;
+  // optional (device): number of queries the matrix-core path could not certify and answered
+  // with the scan kernel instead (0 on the scan path)
+  uint32_t* n_rescanned{nullptr};
 };
 void launch_bf_query(const BfLaunch& a, hipStream_t stream);
 
@@ -206,6 +209,13 @@ void launch_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t 
                           uint32_t id_offset_per_part, const int32_t* parts_ids,
                           const float* parts_dists, int32_t* ids_out, float* dists_out,
                           hipStream_t stream);
+
+// merge_results for the queries qlist[0, *qcount) only (device memory; null = all queries)
+void launch_merge_results_subset(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                 uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                 const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                 const uint32_t* qlist, const uint32_t* qcount,
+                                 hipStream_t stream);
 
 // host layout math (graph_config.cpp)
 void graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild, ggnn_graph_config* out);

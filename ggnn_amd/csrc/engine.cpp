@@ -154,6 +154,7 @@ struct DeviceCtx {
   std::vector<Shard> shards;
   float build_ms{0.f}, query_ms{0.f};
   uint64_t n_dist{0}, n_pop{0}, n_float_rows{0}, n_code_rows{0};
+  DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
 
   DeviceCtx() = default;
   DeviceCtx(const DeviceCtx&) = delete;
@@ -168,6 +169,7 @@ struct DeviceCtx {
     o.stream = nullptr;
     o.ev_a = o.ev_b = nullptr;
     base_copy = std::move(o.base_copy);
+    bf_rescanned = std::move(o.bf_rescanned);
     d_base = o.d_base;
     first_shard = o.first_shard;
     shards = std::move(o.shards);
@@ -227,6 +229,7 @@ struct ggnn_handle {
   // tracing
   float build_ms{0.f}, query_ms{0.f}, bf_ms{0.f};
   uint64_t last_n_dist{0}, last_n_pop{0}, last_float_rows{0}, last_code_rows{0};
+  uint32_t last_bf_rescanned{0};
 
   std::string last_error;
 
@@ -811,11 +814,15 @@ struct ggnn_handle {
       d_ids = r_ids.as<int32_t>();
       d_dists = r_dists.as<float>();
     }
+    if (!ctx.bf_rescanned.p)
+      ctx.bf_rescanned.alloc(sizeof(uint32_t));
     BfLaunch bl{ctx.d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
-                measure,    d_ids,  d_dists};
+                measure,    d_ids,  d_dists,    ctx.bf_rescanned.as<uint32_t>()};
     EventTimer timer(ctx.stream, ctx.ev_a, ctx.ev_b);
     launch_bf_query(bl, ctx.stream);
     bf_ms = timer.stop();
+    GGNN_HIP_CHECK(hipMemcpyAsync(&last_bf_rescanned, ctx.bf_rescanned.p, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, ctx.stream));
     GGNN_LOG(0, "[GPU: %d] brute-force query: => ms: %.3f [%u points query -> %.3f us/point]",
              ctx.device, bf_ms, nq, bf_ms * 1000.f / static_cast<float>(nq));
     if (!direct) {
@@ -1176,6 +1183,14 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
   return GGNN_OK;
 }
 
+ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned)
+{
+  GGNN_NEED_HANDLE(h);
+  if (n_rescanned)
+    *n_rescanned = h->last_bf_rescanned;
+  return GGNN_OK;
+}
+
 ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop)
 {
   GGNN_NEED_HANDLE(h);
@@ -1283,6 +1298,17 @@ ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base
 {
   return guarded(nullptr, [&] {
     BfLaunch b{base, query, dtype, N_base, D, Nq, k_query, measure, ids, dists};
+    launch_bf_query(b, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_bf_query_certified(const void* base, ggnn_dtype dtype, uint32_t N_base,
+                                       uint32_t D, const void* query, uint32_t Nq,
+                                       uint32_t k_query, ggnn_measure measure, int32_t* ids,
+                                       float* dists, uint32_t* n_rescanned, void* stream)
+{
+  return guarded(nullptr, [&] {
+    BfLaunch b{base, query, dtype, N_base, D, Nq, k_query, measure, ids, dists, n_rescanned};
     launch_bf_query(b, static_cast<hipStream_t>(stream));
   });
 }

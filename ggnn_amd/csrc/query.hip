@@ -1,6 +1,9 @@
 // query kernel: best-first graph traversal, one wave64 per query.
 // Reference: QueryKernel::operator(), src/ggnn/query/query_layer.cu:39-97; host sizing
 // QueryKernelsImpl::query, src/ggnn/query/query_kernels.cu:50-186.
+#include <algorithm>
+#include <cstdlib>
+
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -23,6 +26,10 @@ struct QueryArgs {
   const uint8_t* ps_codes;
   const float* ps_params;
   uint32_t ps_Dc;
+  // persistent launch (optional): the grid holds one round of resident waves, each wave takes
+  // further queries from this counter (zero at launch) until Nq is reached
+  uint32_t* work_counter;
+  uint32_t persistent_waves;
 };
 
 template <class PSC, typename BaseT>
@@ -39,16 +46,9 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 #endif
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
-__global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
-query_kernel(const QueryArgs a)
+GGNN_DEV void query_one(const QueryArgs& a, const WaveLds& lds, const uint32_t n)
 {
-  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  const WaveLds lds(lds_raw, a.cache);
   const int lane = threadIdx.x;
-  const uint32_t n = block_linear_index();
-  if (n >= a.Nq)
-    return;
 
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
@@ -132,6 +132,30 @@ query_kernel(const QueryArgs a)
   }
 }
 
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, bool PERSIST = false>
+__global__ void __launch_bounds__(kWave) __attribute__((
+    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
+query_kernel(const QueryArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const WaveLds lds(lds_raw, a.cache);
+  uint32_t n = block_linear_index();
+  if constexpr (!PERSIST) {
+    if (n < a.Nq)
+      query_one<BaseT, LPR, NCH, R, MODE, PSC>(a, lds, n);
+    return;
+  }
+  const uint32_t waves = gridDim.x * gridDim.y;
+  while (n < a.Nq) {
+    query_one<BaseT, LPR, NCH, R, MODE, PSC>(a, lds, n);
+    __syncthreads();
+    uint32_t next = 0;
+    if (threadIdx.x == 0)
+      next = atomicAdd(a.work_counter, 1u);
+    n = waves + static_cast<uint32_t>(uni(static_cast<int>(next)));
+  }
+}
+
 // Same kernel with the LDS-resident list (SORTED > 256, i.e. KQuery > 239).
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
@@ -212,14 +236,19 @@ template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(args.cache);
-  if (sorted <= 64)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
+  const dim3 grid = grid_for(args.work_counter ? std::min<uint64_t>(args.Nq, args.persistent_waves)
+                                               : args.Nq);
+  if (sorted <= 64 && args.work_counter)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, true>), grid, dim3(kWave), lds,
+                       stream, args);
+  else if (sorted <= 64)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid, dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 128)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid, dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 256)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid, dim3(kWave), lds,
                        stream, args);
   else {
     // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
@@ -291,10 +320,24 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
     args.ps_Dc = a.ps_Dc;
   }
 
+  // experiment hook: GGNN_QUERY_PERSIST=<waves per SIMD> launches that many resident waves per SIMD
+  // and lets them pull queries from a counter
+  uint32_t* counter = nullptr;
+  if (const char* e = std::getenv("GGNN_QUERY_PERSIST")) {
+    const int per_simd = std::atoi(e);
+    if (per_simd > 0 && args.sorted <= 64) {
+      GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&counter), sizeof(uint32_t), stream));
+      GGNN_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
+      args.work_counter = counter;
+      args.persistent_waves = 1024u * static_cast<uint32_t>(per_simd);
+    }
+  }
 #define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_QUERY);
 #undef GGNN_LAUNCH_QUERY
   GGNN_HIP_CHECK(hipGetLastError());
+  if (counter)
+    GGNN_HIP_CHECK(hipFreeAsync(counter, stream));
 }
 
 }  // namespace ggnn_amd

@@ -69,11 +69,17 @@ void launch_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, floa
 // one thread per query: k-way merge of num_parts sorted rows (num_parts is small)
 __global__ void merge_results_kernel(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
                                      uint32_t id_offset_per_part, const int32_t* parts_ids,
-                                     const float* parts_dists, int32_t* ids_out, float* dists_out)
+                                     const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                     const uint32_t* qlist, const uint32_t* qcount)
 {
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Nq)
     return;
+  if (qlist) {
+    if (n >= *qcount)
+      return;
+    n = qlist[n];
+  }
   constexpr uint32_t kMaxParts = 64;
   uint32_t pos[kMaxParts];
   float head[kMaxParts];
@@ -111,6 +117,16 @@ void launch_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t 
                           const float* parts_dists, int32_t* ids_out, float* dists_out,
                           hipStream_t stream)
 {
+  launch_merge_results_subset(Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists,
+                              ids_out, dists_out, nullptr, nullptr, stream);
+}
+
+void launch_merge_results_subset(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                 uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                 const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                 const uint32_t* qlist, const uint32_t* qcount,
+                                 hipStream_t stream)
+{
   if (!Nq)
     return;
   GGNN_REQUIRE(num_parts >= 1 && num_parts <= 64, GGNN_INVALID_ARGUMENT,
@@ -120,7 +136,7 @@ void launch_merge_results(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t 
   const uint32_t block = 128;
   hipLaunchKernelGGL(merge_results_kernel, dim3((Nq + block - 1) / block), dim3(block), 0, stream,
                      Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists, ids_out,
-                     dists_out);
+                     dists_out, qlist, qcount);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 

@@ -139,11 +139,18 @@ def query(base, query, graph0, start, nn1_stats, k_query, tau_query, max_iterati
     return ids, dists
 
 
-def bf_query(base, query, k_query, measure=EUCLIDEAN):
+def bf_query(base, query, k_query, measure=EUCLIDEAN, rescanned=False):
+    """rescanned=True: also return how many queries the matrix-core path handed to the scan"""
     _need(base, name="base"), _need(query, base.dtype, "query")
     Nq = query.shape[0]
     ids = torch.empty((Nq, k_query), dtype=torch.int32, device=base.device)
     dists = torch.empty((Nq, k_query), dtype=torch.float32, device=base.device)
+    if rescanned:
+        n = torch.zeros(1, dtype=torch.int32, device=base.device)
+        check(lib().ggnn_op_bf_query_certified(_ptr(base), _dtype_code(base), base.shape[0],
+                                               base.shape[1], _ptr(query), Nq, k_query, measure,
+                                               _ptr(ids), _ptr(dists), _ptr(n), _stream()))
+        return ids, dists, int(n.item())
     check(lib().ggnn_op_bf_query(_ptr(base), _dtype_code(base), base.shape[0], base.shape[1],
                                  _ptr(query), Nq, k_query, measure, _ptr(ids), _ptr(dists),
                                  _stream()))

@@ -128,6 +128,9 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
 /* per-query work counters of the last ggnn_query (sum over queries and shards): number of
  * distance evaluations and of successful pops; used for the roofline figure. */
 ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop);
+/* queries of the last ggnn_bf_query that were answered by the exhaustive scan because the
+ * matrix-core pre-selection could not be certified exact (tracing; results are exact either way) */
+ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned);
 ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
 /* rows the last ggnn_query read for those evaluations (needs collect_counters): float rows
  * (4*D bytes each) and, with the pre-screen, 8-bit code rows (D rounded up to 16 bytes each). */
@@ -207,6 +210,13 @@ ggnn_status ggnn_op_query_prescreened(const float* base, uint32_t N_base, uint32
 ggnn_status ggnn_op_bf_query(const void* base, ggnn_dtype dtype, uint32_t N_base, uint32_t D,
                              const void* query, uint32_t Nq, uint32_t k_query,
                              ggnn_measure measure, int32_t* ids, float* dists, void* stream);
+/* same, and *n_rescanned (device memory, may be NULL) receives the number of queries whose
+ * matrix-core pre-selection could not be certified exact and which were therefore answered by the
+ * exhaustive scan kernel (0 on paths that scan anyway).  The answers are exact either way. */
+ggnn_status ggnn_op_bf_query_certified(const void* base, ggnn_dtype dtype, uint32_t N_base,
+                                       uint32_t D, const void* query, uint32_t Nq,
+                                       uint32_t k_query, ggnn_measure measure, int32_t* ids,
+                                       float* dists, uint32_t* n_rescanned, void* stream);
 
 /* top  graph_construction.cu:201-237 -> top_merge_layer.cu:40-82.  graph_layer/translation are
  * the views of `layer` (translation NULL on layer 0). */

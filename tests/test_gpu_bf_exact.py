@@ -1,0 +1,186 @@
+"""bf_query on the matrix cores must be EXACT -- it is a hot-path function and the recall ground
+truth (reference: BruteForceQueryKernel, src/ggnn/query/bf_query_layer.cu:52-57, exact by
+construction).  The MFMA path pre-selects with the expanded distance form, certifies every query
+with a rounding bound and re-scans the ones it cannot certify (ggnn_amd/csrc/bf_mfma.hip).
+
+Checked here on data chosen to break an un-certified pre-selection (large common offsets, tiny
+scales, rows of very different norms, tight far-away clusters, an outlier row):
+  * bit-identical ids and distances to the scan kernel (same direct-form arithmetic, taken for
+    batches of < 256 queries),
+  * agreement with the CPU oracle up to float rounding of near-ties, judged in float64,
+  * the certificate / re-scan counters behave as designed (centred data is certified, the
+    un-centred test hook and degenerate data are re-scanned -- and still exact).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_int_data, make_uni_data
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ggnn_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _clustered(N, D, seed, offset=0.0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(32, D)) * 4.0
+    x = centres[rng.integers(0, 32, N)] + rng.normal(size=(N, D))
+    return (x * scale + offset).astype(np.float32)
+
+
+def _uni_offset(N, D, seed):
+    return make_uni_data(N, D, seed) + np.float32(1000.0)
+
+
+def _mixed_norms(N, D, seed):
+    """rows of very different lengths (cosine must not care; L2 norms span 12 decades)"""
+    rng = np.random.default_rng(seed)
+    x = _clustered(N, D, seed)
+    return (x * (10.0 ** rng.uniform(-3, 3, (N, 1)))).astype(np.float32)
+
+
+def _far_tight(N, D, seed):
+    """tight clusters (spread 1e-3) around far-apart centres: neighbour distances ~1e-4 next to
+    squared norms ~1e3 even after centring -> cannot be certified, must be re-scanned"""
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(8, D)) * 4.0
+    x = centres[rng.integers(0, 8, N)] + 1e-3 * rng.normal(size=(N, D))
+    return x.astype(np.float32)
+
+
+def _with_outlier(N, D, seed):
+    x = _clustered(N, D, seed)
+    if N > 5000:  # the base only: one row with an enormous norm inflates the bound for everyone
+        x[1234] = 1.0e6
+    return x
+
+
+def scan_answer(ops, b, q, K, measure):
+    """the scan kernel (batches of < 256 queries never take the MFMA path)"""
+    ids, dists = [], []
+    for i in range(0, q.shape[0], 128):
+        a, d = ops.bf_query(b, q[i:i + 128].contiguous(), K, measure)
+        ids.append(a)
+        dists.append(d)
+    return torch.cat(ids), torch.cat(dists)
+
+
+def check_against_float64(base, q, ids, K, measure, rel=2e-6):
+    """no true neighbour may be missing except within float rounding of the K-th distance"""
+    b64, q64 = base.astype(np.float64), q.astype(np.float64)
+    for n in range(0, q.shape[0], 7):
+        if measure == 0:
+            d = ((b64 - q64[n]) ** 2).sum(1)
+        else:
+            nb, nq = np.linalg.norm(b64, axis=1), np.linalg.norm(q64[n])
+            d = np.abs(1.0 - (b64 @ q64[n]) / np.maximum(nb * nq, 1e-300))
+        got = ids[n]
+        assert len(set(got.tolist())) == K
+        kth = np.sort(d)[K - 1]
+        tol = rel * max(kth, 1e-30) + (1e-6 if measure else 0.0)
+        assert d[got].max() <= kth + tol, (n, d[got].max(), kth)
+        # and the rows are in ascending order up to the same rounding
+        assert (np.diff(d[got]) >= -tol).all()
+
+
+CASES = [
+    ("uni+1000", _uni_offset, 0, 128), ("clustered+1000", lambda N, D, s: _clustered(N, D, s, 1000.0), 0, 128),
+    ("clustered*1e-3-5", lambda N, D, s: _clustered(N, D, s, -5.0, 1e-3), 0, 128),
+    ("clustered+1000 D=96", lambda N, D, s: _clustered(N, D, s, 1000.0), 0, 96),
+    ("clustered+1000 D=200", lambda N, D, s: _clustered(N, D, s, 1000.0), 0, 200),
+    ("clustered+300 D=960", lambda N, D, s: _clustered(N, D, s, 300.0), 0, 960),
+    ("mixed norms cosine", _mixed_norms, 1, 128), ("mixed norms cosine D=960", _mixed_norms, 1, 960),
+    ("clustered+1000 cosine", lambda N, D, s: _clustered(N, D, s, 1000.0), 1, 128),
+    ("mixed norms L2", _mixed_norms, 0, 128), ("outlier row", _with_outlier, 0, 128),
+]
+
+
+@pytest.mark.parametrize("name,maker,measure,D", CASES, ids=[c[0] for c in CASES])
+def test_bf_mfma_adversarial_equals_scan(ops, orc, name, maker, measure, D):
+    N, Nq, K = (20000, 300, 10) if D <= 256 else (8000, 256, 10)
+    base, q = maker(N, D, 501), maker(Nq, D, 502)
+    b, qq = dev(base), dev(q)
+    ids, dists, rescanned = ops.bf_query(b, qq, K, measure, rescanned=True)
+    s_ids, s_dists = scan_answer(ops, b, qq, K, measure)
+    assert torch.equal(ids, s_ids), name
+    assert torch.equal(dists, s_dists), name
+    check_against_float64(base, q, ids.cpu().numpy(), K, measure)
+    # the oracle agrees wherever its own (differently ordered) float sums do not reorder near-ties
+    o_ids, o_d = orc.bf_query(base, q[:64], K, measure)
+    np.testing.assert_allclose(dists[:64].cpu().numpy(), o_d, rtol=1e-4, atol=1e-6 if measure else 0)
+    if name in ("uni+1000", "clustered+1000", "clustered*1e-3-5", "clustered+1000 D=96"):
+        assert rescanned == 0, (name, rescanned)   # centring makes these certifiable
+
+
+def test_bf_mfma_uncertifiable_data_is_rescanned(ops, orc):
+    """tight far clusters: the bound cannot separate the K-th from the (K+8)-th neighbour, so the
+    queries are answered by the scan kernel -- correct, just not fast"""
+    N, Nq, K, D = 20000, 300, 10, 128
+    base, q = _far_tight(N, D, 511), _far_tight(Nq, D, 512)
+    b, qq = dev(base), dev(q)
+    ids, dists, rescanned = ops.bf_query(b, qq, K, 0, rescanned=True)
+    s_ids, s_dists = scan_answer(ops, b, qq, K, 0)
+    assert torch.equal(ids, s_ids) and torch.equal(dists, s_dists)
+    assert rescanned > Nq // 2
+    check_against_float64(base, q, ids.cpu().numpy(), K, 0, rel=1e-5)
+
+
+def test_bf_mfma_without_centring_falls_back_and_stays_exact(ops):
+    """GGNN_BF_NO_CENTER=1 (test hook): offset data is no longer certifiable -> every query is
+    re-scanned; with centring none is.  Results identical in all three runs."""
+    N, Nq, K, D = 20000, 300, 10, 128
+    base, q = _clustered(N, D, 521, 1000.0), _clustered(Nq, D, 522, 1000.0)
+    b, qq = dev(base), dev(q)
+    ids, dists, r0 = ops.bf_query(b, qq, K, 0, rescanned=True)
+    os.environ["GGNN_BF_NO_CENTER"] = "1"
+    try:
+        ids2, dists2, r1 = ops.bf_query(b, qq, K, 0, rescanned=True)
+    finally:
+        del os.environ["GGNN_BF_NO_CENTER"]
+    s_ids, s_dists = scan_answer(ops, b, qq, K, 0)
+    assert r0 == 0 and r1 == Nq
+    for a, d in ((ids, dists), (ids2, dists2)):
+        assert torch.equal(a, s_ids) and torch.equal(d, s_dists)
+
+
+@pytest.mark.parametrize("K", [1, 10, 100])
+def test_bf_mfma_integer_data_certified_and_exact(ops, orc, K):
+    """the S-int track: still bit-identical to the oracle, and nothing needs the re-scan"""
+    base, q = make_int_data(30000, 128, 531), make_int_data(300, 128, 532)
+    ids, dists, rescanned = ops.bf_query(dev(base), dev(q), K, 0, rescanned=True)
+    o_ids, o_d = orc.bf_query(base, q, K)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(dists.cpu().numpy(), o_d)
+    assert rescanned <= 3
+
+
+def test_bf_mfma_duplicate_rows_ties(ops, orc):
+    """every distance occurs three times and some queries are base rows (d = 0): ties at the
+    boundary of the candidate lists cannot be certified strictly -> re-scan keeps Q2 order"""
+    base = make_int_data(3000, 64, 3)
+    base = np.concatenate([base, base, base])
+    q = np.concatenate([make_int_data(200, 64, 4), base[:100]])
+    ids, dists, rescanned = ops.bf_query(dev(base), dev(q), 12, 0, rescanned=True)
+    o_ids, o_d = orc.bf_query(base, q, 12)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(dists.cpu().numpy(), o_d)
+
+
+def test_engine_reports_rescanned_queries(orc):
+    import ggnn_amd as ggnn
+    base, q = _clustered(20000, 128, 541, 1000.0), _clustered(300, 128, 542, 1000.0)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    gt, gd = eng.bf_query(q, 10)
+    assert eng.last_bf_query_rescanned() == 0
+    check_against_float64(base, q, gt.numpy(), 10, 0)
