@@ -71,25 +71,48 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
   constexpr int EPC = ChunkOf<BaseT>::EPC;
   using Chunk = typename ChunkOf<BaseT>::type;
   const uint32_t g = threadIdx.x & 15;
-  const uint32_t row = block_linear_index() * 16 + (threadIdx.x >> 4);
-  float acc = 0.f;
-  if (row < N) {
-    const BaseT* p = data + static_cast<size_t>(row) * D;
+  float vmax = 0.f;
+  // grid-stride over groups of 16 rows (one row per 16 lanes, 16 bytes per lane and step)
+  for (uint64_t row = static_cast<uint64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); row < N;
+       row += static_cast<uint64_t>(gridDim.x) * 16) {
+    const BaseT* p = data + row * D;
+    float acc = 0.f;
     for (uint32_t e0 = g * EPC; e0 < D; e0 += 16 * EPC) {
       const Chunk v = *reinterpret_cast<const Chunk*>(p + e0);
+      float m[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        m[e] = SHIFT ? 128.f : 0.f;
+      if constexpr (!SHIFT && EPC == 4) {
+        if (mean) {
+          const float4 mv = *reinterpret_cast<const float4*>(mean + e0);
+          m[0] = mv.x, m[1] = mv.y, m[2] = mv.z, m[3] = mv.w;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const float x = ChunkOf<BaseT>::get(v, e) - (SHIFT ? 128.f : (mean ? mean[e0 + e] : 0.f));
+        const float x = ChunkOf<BaseT>::get(v, e) - m[e];
         acc = fmaf(x, x, acc);
       }
     }
+    acc = group_sum<16>(acc);
+    if (g == 0)
+      out[row] = acc;
+    vmax = fmaxf(vmax, acc);
   }
-  acc = group_sum<16>(acc);
-  if (row < N && g == 0) {
-    out[row] = acc;
-    if (max_out)
-      atomicMax(max_out, __float_as_uint(acc));
+  if (max_out) {
+    // one atomic per wave (a million atomics on one address take milliseconds)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(max_out, __float_as_uint(vmax));
   }
+}
+
+inline uint32_t norm_grid(uint32_t rows)
+{
+  return std::max(1u, std::min((rows + 15u) / 16u, 8192u));
 }
 
 // Column means of (a sample of) the base: partial[p][c] = sum over rows p, p+P, ... of the
@@ -102,10 +125,17 @@ __global__ void __launch_bounds__(256) col_mean_partial_kernel(const float* data
                                                               uint32_t rows, float* partial)
 {
   for (uint32_t c = threadIdx.x; c < D; c += 256) {
-    float acc = 0.f;
-    for (uint32_t r = blockIdx.x; r < rows; r += kBfMeanBlocks)
-      acc += data[static_cast<size_t>(r) * stride * D + c];
-    partial[blockIdx.x * D + c] = acc;
+    // four independent chains: the loop is a sequence of dependent-latency loads otherwise
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t r = blockIdx.x;
+    for (; r + 3 * kBfMeanBlocks < rows; r += 4 * kBfMeanBlocks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] += data[static_cast<size_t>(r + j * kBfMeanBlocks) * stride * D + c];
+    }
+    for (; r < rows; r += kBfMeanBlocks)
+      acc[0] += data[static_cast<size_t>(r) * stride * D + c];
+    partial[blockIdx.x * D + c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
 }
 __global__ void __launch_bounds__(256) col_mean_final_kernel(const float* partial, uint32_t D,
@@ -883,8 +913,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
 
   if (center) {
-    // at most ~128k evenly spaced rows: enough for a shift, cheap next to the scan itself
-    const uint32_t stride = std::max(1u, a.N_base / 65536u);
+    // at most ~32k evenly spaced rows: plenty for a shift, negligible next to the scan itself
+    const uint32_t stride = std::max(1u, a.N_base / 16384u);
     const uint32_t rows = (a.N_base + stride - 1) / stride;
     hipLaunchKernelGGL(col_mean_partial_kernel, dim3(kBfMeanBlocks), dim3(256), 0, stream,
                        static_cast<const float*>(a.base), a.N_base, a.D, stride, rows, partial);
@@ -934,9 +964,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
 
 #define GGNN_BF_MFMA(T, MODE_)                                                                    \
   do {                                                                                            \
-    hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,   \
+    hipLaunchKernelGGL((row_norms_kernel<T>), dim3(norm_grid(a.N_base)), dim3(256), 0, stream,   \
                        static_cast<const T*>(a.base), a.N_base, a.D, d_mean, bnorm, flags);       \
-    hipLaunchKernelGGL((row_norms_kernel<T>), grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,       \
+    hipLaunchKernelGGL((row_norms_kernel<T>), dim3(norm_grid(a.Nq)), dim3(256), 0, stream,       \
                        static_cast<const T*>(a.query), a.Nq, a.D, d_mean, qnorm,                  \
                        static_cast<uint32_t*>(nullptr));                                          \
     const void* kern = (a.D > 128) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>)   \
@@ -951,11 +981,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   } while (0)
   if (use_i8) {
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
-                       grid_for((static_cast<uint64_t>(a.N_base) + 15) / 16), dim3(256), 0, stream,
+                       dim3(norm_grid(a.N_base)), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.base), a.N_base, a.D,
                        static_cast<const float*>(nullptr), bnorm, flags);
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
-                       grid_for((static_cast<uint64_t>(a.Nq) + 15) / 16), dim3(256), 0, stream,
+                       dim3(norm_grid(a.Nq)), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.query), a.Nq, a.D,
                        static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr));
     const size_t lds8 = 2 * kBfI8Tiles * kBfTileRows * kBfI8RowStride +

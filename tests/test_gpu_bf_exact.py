@@ -55,7 +55,7 @@ def _far_tight(N, D, seed):
     """tight clusters (spread 1e-3) around far-apart centres: neighbour distances ~1e-4 next to
     squared norms ~1e3 even after centring -> cannot be certified, must be re-scanned"""
     rng = np.random.default_rng(seed)
-    centres = rng.normal(size=(8, D)) * 4.0
+    centres = np.random.default_rng(99).normal(size=(8, D)) * 4.0  # the same for base and queries
     x = centres[rng.integers(0, 8, N)] + 1e-3 * rng.normal(size=(N, D))
     return x.astype(np.float32)
 
