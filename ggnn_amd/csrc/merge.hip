@@ -22,7 +22,13 @@ struct MergeArgs {
   const uint8_t* ps_codes;
   const float* ps_params;
   uint32_t ps_Dc;
+  uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
 };
+
+// occupancy target of the common instantiations (as for the query kernel): a tuning knob
+#ifndef GGNN_MERGE_WAVES
+#define GGNN_MERGE_WAVES 7
+#endif
 
 constexpr uint32_t kMergeCache = 256;      // merge_layer.cuh:44
 constexpr uint32_t kMergeIterations = 200; // merge_layer.cuh:43
@@ -33,8 +39,10 @@ uint32_t merge_sorted_size(uint32_t KBuild)
   return std::max(64u, next_multiple32(KBuild + 1 + 16));
 }
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
-__global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
+__global__ void __launch_bounds__(kWave)
+    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_MERGE_WAVES : 1)))
+    merge_kernel(const MergeArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kMergeCache);
@@ -63,8 +71,8 @@ __global__ void __launch_bounds__(kWave) merge_kernel(const MergeArgs a)
             a.D);
   uint2 rows_read = make_uint2(0u, 0u);
 
-  SortedList<R> sl;
-  sl.init(K + 1, a.sorted, kMergeCache, xi, lds.known);
+  SortedList<R, HB> sl;
+  sl.init(K + 1, a.sorted, kMergeCache, xi, lds.known, static_cast<int>(a.vis_slots));
   uint32_t cnt_dist = 0;
 
   {
@@ -171,7 +179,12 @@ template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kMergeCache);
-  if (args.sorted <= 64)
+  // visited ring of 192 entries mirrored in a hash set (traversal.hpp) where the registers allow
+  // it at 7 waves per SIMD (see launch_query_r)
+  if (args.sorted <= 64 && (PSC::enabled || NCH == 1))
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.N_btm), dim3(kWave),
+                       wave_lds_bytes(kMergeCache, 1), stream, args);
+  else if (args.sorted <= 64)
     hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 128)
@@ -233,6 +246,7 @@ void launch_merge(const MergeLaunch& a, hipStream_t stream)
     args.STs_off[l] = c.STs_offsets[l];
   }
   args.tau = a.tau_build;
+  args.vis_slots = vis_slots_from_env();
   GGNN_REQUIRE(args.sorted < kMergeCache, GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
   if (!args.N_btm)
     return;

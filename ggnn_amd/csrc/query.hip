@@ -1,9 +1,6 @@
 // query kernel: best-first graph traversal, one wave64 per query.
 // Reference: QueryKernel::operator(), src/ggnn/query/query_layer.cu:39-97; host sizing
 // QueryKernelsImpl::query, src/ggnn/query/query_kernels.cu:50-186.
-#include <algorithm>
-#include <cstdlib>
-
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -26,10 +23,7 @@ struct QueryArgs {
   const uint8_t* ps_codes;
   const float* ps_params;
   uint32_t ps_Dc;
-  // persistent launch (optional): the grid holds one round of resident waves, each wave takes
-  // further queries from this counter (zero at launch) until Nq is reached
-  uint32_t* work_counter;
-  uint32_t persistent_waves;
+  uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
 };
 
 template <class PSC, typename BaseT>
@@ -45,10 +39,17 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 #define GGNN_QUERY_WAVES 7
 #endif
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
-GGNN_DEV void query_one(const QueryArgs& a, const WaveLds& lds, const uint32_t n)
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
+__global__ void __launch_bounds__(kWave) __attribute__((
+    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
+query_kernel(const QueryArgs a)
 {
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const WaveLds lds(lds_raw, a.cache);
   const int lane = threadIdx.x;
+  const uint32_t n = block_linear_index();
+  if (n >= a.Nq)
+    return;
 
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
@@ -62,8 +63,8 @@ GGNN_DEV void query_one(const QueryArgs& a, const WaveLds& lds, const uint32_t n
   PSC ps;
   load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
-  SortedList<R> sl;
-  sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known);
+  SortedList<R, HB> sl;
+  sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots));
 
   uint32_t cnt_dist = 0, cnt_pop = 0;
   uint2 cnt_rows = make_uint2(0u, 0u);
@@ -129,30 +130,6 @@ GGNN_DEV void query_one(const QueryArgs& a, const WaveLds& lds, const uint32_t n
       a.n_pop[n] = cnt_pop;
     if (a.n_rows)
       a.n_rows[n] = cnt_rows;
-  }
-}
-
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, bool PERSIST = false>
-__global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
-query_kernel(const QueryArgs a)
-{
-  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  const WaveLds lds(lds_raw, a.cache);
-  uint32_t n = block_linear_index();
-  if constexpr (!PERSIST) {
-    if (n < a.Nq)
-      query_one<BaseT, LPR, NCH, R, MODE, PSC>(a, lds, n);
-    return;
-  }
-  const uint32_t waves = gridDim.x * gridDim.y;
-  while (n < a.Nq) {
-    query_one<BaseT, LPR, NCH, R, MODE, PSC>(a, lds, n);
-    __syncthreads();
-    uint32_t next = 0;
-    if (threadIdx.x == 0)
-      next = atomicAdd(a.work_counter, 1u);
-    n = waves + static_cast<uint32_t>(uni(static_cast<int>(next)));
   }
 }
 
@@ -236,19 +213,26 @@ template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(args.cache);
-  const dim3 grid = grid_for(args.work_counter ? std::min<uint64_t>(args.Nq, args.persistent_waves)
-                                               : args.Nq);
-  if (sorted <= 64 && args.work_counter)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, true>), grid, dim3(kWave), lds,
-                       stream, args);
+  // one list register per lane: the visited ring is mirrored in a hash set (traversal.hpp) when it
+  // is short enough for one or two bucket registers
+  // (not for the two-chunk float layouts without pre-screen: four rows of two chunks in flight leave
+  // no register for it at 7 waves per SIMD -- measured 2.73 vs 2.54 ms with the spills)
+  const bool fits = PSC::enabled || NCH == 1;
+  const uint32_t hb = (sorted <= 64 && fits) ? vis_hash_regs(args.cache - sorted) : 0;
+  if (hb == 1)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.Nq), dim3(kWave),
+                       wave_lds_bytes(args.cache, 1), stream, args);
+  else if (hb == 2)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2>), grid_for(args.Nq), dim3(kWave),
+                       wave_lds_bytes(args.cache, 2), stream, args);
   else if (sorted <= 64)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid, dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 128)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid, dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else if (sorted <= 256)
-    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid, dim3(kWave), lds,
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
   else {
     // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
@@ -308,6 +292,7 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.shards_per_gpu = a.shards_per_gpu;
   args.on_gpu_shard = a.on_gpu_shard;
   args.tau = a.tau_query;
+  args.vis_slots = vis_slots_from_env();
   const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
     GGNN_REQUIRE(a.ps_Dc % 16 == 0 && a.ps_Dc >= a.D && a.ps_Dc < a.D + 16,
@@ -320,24 +305,10 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
     args.ps_Dc = a.ps_Dc;
   }
 
-  // experiment hook: GGNN_QUERY_PERSIST=<waves per SIMD> launches that many resident waves per SIMD
-  // and lets them pull queries from a counter
-  uint32_t* counter = nullptr;
-  if (const char* e = std::getenv("GGNN_QUERY_PERSIST")) {
-    const int per_simd = std::atoi(e);
-    if (per_simd > 0 && args.sorted <= 64) {
-      GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&counter), sizeof(uint32_t), stream));
-      GGNN_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-      args.work_counter = counter;
-      args.persistent_waves = 1024u * static_cast<uint32_t>(per_simd);
-    }
-  }
 #define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_QUERY);
 #undef GGNN_LAUNCH_QUERY
   GGNN_HIP_CHECK(hipGetLastError());
-  if (counter)
-    GGNN_HIP_CHECK(hipFreeAsync(counter, stream));
 }
 
 }  // namespace ggnn_amd

@@ -14,6 +14,7 @@
 // gathers), then the accept/push sequence is replayed in candidate order, which is what the
 // reference does one candidate at a time (simple_knn_cache.cuh:268-286).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -81,9 +82,10 @@ GGNN_DEV float group_sum(float v)
   return v;
 }
 
-// LDS layout of one wave (ints): known[CACHE] | ckeys[32] | cd0[32] | cd1[32]
+// LDS layout of one wave (ints): known[CACHE] | ckeys[32] | cd0[32] | cd1[32] | [hashed visited set]
 //   known[0,SORTED)        copy of the sorted keys, refreshed at every filtered fetch
 //   known[SORTED,CACHE)    visited ring (reference: s_cache[SORTED_SIZE..CACHE_SIZE))
+//   buckets[64*HB][8] | stash[32]   only for SortedList<R, HB> with HB > 0 (see there)
 struct WaveLds {
   int* known;
   int* ckeys;
@@ -96,9 +98,18 @@ struct WaveLds {
   }
   static constexpr size_t extra_ints = 96;
 };
-inline size_t wave_lds_bytes(uint32_t cache)
+constexpr int kVisSlots = 8;    // keys per bucket of the hashed visited set
+constexpr int kVisStash = 32;   // overflow entries before the filter falls back to the ring scan
+inline size_t wave_lds_bytes(uint32_t cache, uint32_t hash_regs = 0)
 {
-  return (cache + WaveLds::extra_ints) * sizeof(int);
+  const size_t hash_ints = hash_regs ? hash_regs * 64 * kVisSlots + kVisStash : 0;
+  return (cache + WaveLds::extra_ints + hash_ints) * sizeof(int);
+}
+// bucket registers of the hashed visited set for a visited ring of `vis` entries: ~3 keys per
+// bucket on average when the ring is full; 0 = rings too long for it (the filter scans the ring)
+inline uint32_t vis_hash_regs(uint32_t vis)
+{
+  return vis <= 192 ? 1u : vis <= 480 ? 2u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,8 +119,20 @@ inline size_t wave_lds_bytes(uint32_t cache)
 // (Q2: a new equal distance goes first), push_best_stable() the KBestList's (k_best_list.cuh:
 // 92-103: equal distances keep insertion order).
 // ---------------------------------------------------------------------------------------------
-template <int R>
+// HB > 0: the visited ring is mirrored in an exact hash set so that the membership test of a fetch
+// (simple_knn_cache.cuh:246-261 scans the whole cache for every candidate) is one bucket read
+// per candidate instead of a scan of up to CACHE entries:
+//   * 64*HB buckets of kVisSlots keys in LDS; lane b of hcnt[b >> 6] counts bucket b, so an
+//     insert (one per pop, the key is wave-uniform) needs no LDS read;
+//   * a key whose bucket is full goes to a small stash that every probe scans (normally empty);
+//   * if the stash overflows too, scan_mode switches the filter back to the ring scan for the rest
+//     of the search -- the ring is always maintained, so the answer is exact in every case;
+//   * when the ring wraps (more pops than ring entries) the overwritten key is removed again.
+// The set of keys reported as known is exactly the reference's: sorted part + visited ring.
+template <int R, int HB = 0>
 struct SortedList {
+  static constexpr int kHashRegs = HB;
+  static constexpr int NB = 64 * HB;
   int key[R];
   float dist[R];
   int BEST, SORTED, P, VIS;
@@ -117,17 +140,44 @@ struct SortedList {
   int vis_head;   // r0_visited_head - SORTED
   int vis_count;  // valid entries of the visited ring
   float xi;
+  int hcnt[HB > 0 ? HB : 1];  // lane b: number of keys in bucket b (+64 per register)
+  int stash_n;
+  int scan_mode;
+  int slots;                  // usable keys per bucket (kVisSlots; tests shrink it)
+  int* hbuckets;
+  int* hstash;
 
-  GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* known)
+  GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* known,
+                     int usable_slots = kVisSlots)
   {
     BEST = best;
     SORTED = sorted;
     P = sorted - best;
     VIS = cache - sorted;
     xi = xi_;
+    slots = usable_slots;
+    hbuckets = known + cache + static_cast<int>(WaveLds::extra_ints);
+    hstash = hbuckets + NB * kVisSlots;
     reset(known);
   }
-  // simple_knn_cache.cuh:73-87
+  // visited ring (and its hashed mirror) empty, simple_knn_cache.cuh:73-87
+  GGNN_DEV void clear_visited(int* known)
+  {
+    vis_head = 0;
+    vis_count = 0;
+    for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
+      known[i] = kEmptyKey;
+    if constexpr (HB > 0) {
+      int4* hb = reinterpret_cast<int4*>(hbuckets);
+      for (int i = threadIdx.x; i < NB * kVisSlots / 4; i += kWave)
+        hb[i] = make_int4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
+#pragma unroll
+      for (int r = 0; r < (HB > 0 ? HB : 1); ++r)
+        hcnt[r] = 0;
+      stash_n = 0;
+      scan_mode = 0;
+    }
+  }
   GGNN_DEV void reset(int* known)
   {
 #pragma unroll
@@ -136,10 +186,80 @@ struct SortedList {
       dist[r] = inf_f();
     }
     head_in = 0;
-    vis_head = 0;
-    vis_count = 0;
-    for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
-      known[i] = kEmptyKey;
+    clear_visited(known);
+  }
+
+  // bucket of a key: 24-bit multiplicative hash (v_mul_u32_u24 is full rate), top bits
+  static GGNN_DEV uint32_t vis_hash(uint32_t k)
+  {
+    k ^= k >> 20;
+    const uint32_t h = __umul24(k, 0x9E3779u);
+    return HB == 2 ? (h >> 25) : (h >> 26);
+  }
+  GGNN_DEV int bucket_count(uint32_t b) const
+  {
+    if constexpr (HB == 2)
+      return (b >> 6) ? rdlane(hcnt[1], b & 63) : rdlane(hcnt[0], b & 63);
+    return rdlane(hcnt[0], b & 63);
+  }
+  GGNN_DEV void bucket_add(uint32_t b, int delta)
+  {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < (HB > 0 ? HB : 1); ++r)
+      if (lane + 64 * r == static_cast<int>(b))
+        hcnt[r] += delta;
+  }
+  // k: wave-uniform key that has just entered the visited ring
+  GGNN_DEV void vis_insert(int k)
+  {
+    const uint32_t b = vis_hash(static_cast<uint32_t>(k));
+    const int c = bucket_count(b);
+    if (c < slots) {
+      if (threadIdx.x == 0)
+        hbuckets[b * kVisSlots + c] = k;
+      bucket_add(b, 1);
+    }
+    else if (stash_n < kVisStash) {
+      if (threadIdx.x == 0)
+        hstash[stash_n] = k;
+      ++stash_n;
+    }
+    else
+      scan_mode = 1;  // the ring scan takes over; the set is no longer maintained
+  }
+  // k: wave-uniform key that the ring is about to overwrite (it is in the set exactly once)
+  GGNN_DEV void vis_remove(int k)
+  {
+    const int lane = threadIdx.x;
+    const uint32_t b = vis_hash(static_cast<uint32_t>(k));
+    const int c = bucket_count(b);
+    __syncthreads();
+    const int v = (lane < c) ? hbuckets[b * kVisSlots + lane] : -2;
+    const unsigned long long hit = __ballot(v == k);
+    if (hit) {
+      const int p = __ffsll(static_cast<long long>(hit)) - 1;
+      const int last = hbuckets[b * kVisSlots + c - 1];
+      __syncthreads();
+      if (lane == 0) {
+        hbuckets[b * kVisSlots + p] = last;
+        hbuckets[b * kVisSlots + c - 1] = kEmptyKey;
+      }
+      bucket_add(b, -1);
+    }
+    else {
+      const int sv = (lane < stash_n) ? hstash[lane] : -2;
+      const unsigned long long shit = __ballot(sv == k);
+      if (shit) {
+        const int p = __ffsll(static_cast<long long>(shit)) - 1;
+        const int last = hstash[stash_n - 1];
+        __syncthreads();
+        if (lane == 0)
+          hstash[p] = last;
+        --stash_n;
+      }
+    }
+    __syncthreads();
   }
 
   GGNN_DEV float dist_at(int i) const
@@ -251,6 +371,13 @@ struct SortedList {
     const float d0 = dist_at(BEST);
     if (k0 == kEmptyKey || d0 >= crit)
       return kEmptyKey;
+    if constexpr (HB > 0) {
+      if (!scan_mode) {
+        if (vis_count == VIS)  // the ring wraps: its oldest key is forgotten
+          vis_remove(uni(known[SORTED + vis_head]));
+        vis_insert(k0);
+      }
+    }
     if (threadIdx.x == 0)
       known[SORTED + vis_head] = k0;
     vis_head = (vis_head + 1 >= VIS) ? 0 : vis_head + 1;
@@ -308,10 +435,7 @@ struct SortedList {
     }
     __syncthreads();
     head_in = 0;
-    vis_head = 0;
-    vis_count = 0;
-    for (int i = SORTED + lane; i < SORTED + VIS; i += kWave)
-      known[i] = kEmptyKey;
+    clear_visited(known);
   }
 
   // filter part of fetch(): simple_knn_cache.cuh:246-261 / simple_knn_sym_cache.cuh:408-419.
@@ -327,7 +451,9 @@ struct SortedList {
         known[i] = key[r];
     }
     __syncthreads();
-    const int E = SORTED + vis_count;
+    // with the hashed set only the sorted part is scanned; the visited ring is one bucket read
+    const bool hashed = (HB > 0) && !scan_mode;
+    const int E = hashed ? SORTED : SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
     // min over (entry XOR cand) is 0 iff some entry equals cand.  Pure VALU on purpose: the
@@ -339,6 +465,15 @@ struct SortedList {
       return min(min(acc, static_cast<unsigned>(e.z) ^ c), static_cast<unsigned>(e.w) ^ c);
     };
     unsigned acc0 = 0xffffffffu, acc1 = 0xffffffffu;
+    if constexpr (HB > 0) {
+      if (hashed) {
+        // lanes j and j+32 hold candidate j: each reads one half of its bucket
+        const uint32_t b = vis_hash(c);
+        acc1 = fold(acc1, *reinterpret_cast<const int4*>(hbuckets + b * kVisSlots + 4 * h));
+        for (int t = 0; t < stash_n; ++t)
+          acc1 = min(acc1, static_cast<unsigned>(hstash[t]) ^ c);
+      }
+    }
     const int4* p = kp + h;
     const int T = (E + 7) >> 3;  // >= 4: SORTED >= 32
     // the reads of the next pair are issued before the current pair is folded: a lone wave
@@ -1015,6 +1150,18 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
 {
   uint2 rows = make_uint2(0u, 0u);
   return fetch<MODE, FILTER>(sl, de, lds, cand, translation, NoPrescreen{}, rows);
+}
+
+// GGNN_VIS_SLOTS=<1..8>: test hook that shrinks the buckets of the hashed visited set so that the
+// stash, its overflow into the ring scan and the removal paths are exercised by ordinary searches
+inline uint32_t vis_slots_from_env()
+{
+  if (const char* e = std::getenv("GGNN_VIS_SLOTS")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= kVisSlots)
+      return static_cast<uint32_t>(v);
+  }
+  return kVisSlots;
 }
 
 // block-size / chunk configuration by dimension and element type (host side)

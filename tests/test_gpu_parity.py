@@ -117,7 +117,8 @@ def test_bf_query_uint8_matrix_path(ops, orc, N, D, Nq, K):
 # overwritten in ring order and leave the visited hash set again
 @pytest.mark.parametrize("K,tau,iters", [(10, 0.34, 200), (10, 0.64, 400), (1, 0.5, 100),
                                          (40, 0.6, 400), (100, 0.6, 512), (10, 0.9, 1000),
-                                         (10, 2.5, 250), (24, 3.0, 255)])
+                                         (10, 2.5, 250), (24, 3.0, 255), (10, 3.0, 512),
+                                         (40, 3.0, 500)])
 def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
     g = small_graph
     q = make_int_data(128, g["D"], 4321)
@@ -132,6 +133,53 @@ def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
     assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
     if iters in (250, 255):
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the visited ring"
+    if iters in (500, 512):
+        assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
+
+
+# The visited ring is mirrored in a hash set (traversal.hpp, SortedList<R, HB>): buckets of 8 keys,
+# a stash for keys whose bucket is full, the ring scan when the stash overflows, removal when the
+# ring wraps.  GGNN_VIS_SLOTS shrinks the buckets so that ordinary searches take all of these paths:
+# 1-2 slots overflow the stash (ring scan takes over), 4 slots fill it without overflowing (keys
+# are removed from buckets AND stash when the ring wraps).  Results and counters must not change.
+@pytest.mark.parametrize("slots", [1, 2, 4])
+@pytest.mark.parametrize("K,tau,iters", [(10, 0.64, 200), (10, 2.5, 250), (24, 3.0, 255),
+                                         (10, 0.64, 400), (10, 3.0, 512), (40, 3.0, 500)])
+def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, iters, monkeypatch):
+    g = small_graph
+    q = make_int_data(96, g["D"], 4322)
+    graph0 = g["graph"][:g["N"]]
+    o_ids, o_d, o_nd, o_np = orc.query(g["base"], q, graph0, start_points(g), g["stats"], K, tau,
+                                       iters, counters=True)
+    monkeypatch.setenv("GGNN_VIS_SLOTS", str(slots))
+    # the pre-screened float kernel is the one that carries the hash set (the plain two-chunk
+    # float kernel keeps the ring scan, see launch_query_r)
+    b = dev(g["base"])
+    ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]), K,
+                                 tau, iters, counters=True, prescreen=ops.prescreen_encode(b))
+    assert np.array_equal(ids.cpu().numpy(), o_ids)
+    assert np.array_equal(d.cpu().numpy(), o_d)
+    assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
+    assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+    if iters in (250, 255):
+        assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the 192-entry ring"
+    if iters in (500, 512):
+        assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
+
+
+@pytest.mark.parametrize("slots", [1, 4])
+@pytest.mark.parametrize("top,btm", [(3, 0), (2, 1)])
+def test_merge_visited_hash_paths_exact(ops, orc, small_graph, slots, top, btm, monkeypatch):
+    g = small_graph
+    c = g["cfg"]
+    o_gb, o_nn1, o_nd = orc.merge(g["base"], c, g["graph"], g["tr"], g["sel"], g["stats"], 0.5,
+                                  top, btm, counters=True)
+    monkeypatch.setenv("GGNN_VIS_SLOTS", str(slots))
+    b = dev(g["base"])
+    gb, nn1, nd = ops.merge(b, c, dev(g["graph"]), dev(g["tr"]), dev(g["sel"]), dev(g["stats"]),
+                            0.5, top, btm, counters=True, prescreen=ops.prescreen_encode(b))
+    assert np.array_equal(gb.cpu().numpy(), o_gb)
+    assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
 
 
 def test_query_shard_offsets(ops, orc, small_graph):
