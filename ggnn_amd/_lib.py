@@ -98,6 +98,7 @@ SIGNATURES = {
     "ggnn_op_bf_query_certified": (_int, [_vp, _int, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp,
                                           _vp, _vp]),
     "ggnn_last_bf_query_rescanned": (_int, [_vp, C.POINTER(_u32)]),
+    "ggnn_last_exchange": (C.c_char_p, [_vp]),
     "ggnn_op_top": (_int, [_vp, _int, _u32, _int, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp,
                            _vp]),
     "ggnn_op_merge": (_int, [_vp, _int, _int, _cfgp, _vp, _vp, _vp, _vp, _f32, _u32, _u32, _vp,

@@ -337,6 +337,10 @@ class GGNN:
         extension: same results, less memory traffic; costs N x D bytes per shard)."""
         self._check(lib().ggnn_set_prescreen(self._h, int(bool(enable))))
 
+    def last_exchange(self):
+        """how the last query combined per-GPU results: "none", "rccl" or "copy" """
+        return lib().ggnn_last_exchange(self._h).decode()
+
     def last_bf_query_rescanned(self):
         """queries of the last bf_query answered by the exhaustive scan because the matrix-core
         pre-selection could not be certified exact (results are exact either way)"""

@@ -217,6 +217,14 @@ void launch_merge_results_subset(uint32_t Nq, uint32_t k, uint32_t num_parts, ui
                                  const uint32_t* qlist, const uint32_t* qcount,
                                  hipStream_t stream);
 
+// ... and for the queries [first, first + count) only (every GPU of a multi-GPU handle merges its
+// own slice of the query set); outputs are indexed by the query number
+void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                const uint32_t* qlist, const uint32_t* qcount, uint32_t first,
+                                uint32_t count, hipStream_t stream);
+
 // host layout math (graph_config.cpp)
 void graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild, ggnn_graph_config* out);
 void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_t* cache_size,

@@ -7,6 +7,9 @@
 // the reference's GPU<->CPU<->disk swapping is not reproduced; one engine drives one GPU
 // (multi-GPU = one process per GPU, shards exchanged with an RCCL all-gather, see
 // ggnn_amd/distributed.py and DESIGN.md).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +145,52 @@ struct DeviceRestoreGuard {
   }
 };
 
+// RCCL entry points, resolved at run time the first time a handle that drives several GPUs
+// exchanges results: single-GPU use never loads the library (torch ships its own copy of
+// librccl.so.1; the loader hands back that copy when it is already in the process).
+struct Rccl {
+  decltype(&ncclCommInitAll) CommInitAll{nullptr};
+  decltype(&ncclCommDestroy) CommDestroy{nullptr};
+  decltype(&ncclAllGather) AllGather{nullptr};
+  decltype(&ncclGroupStart) GroupStart{nullptr};
+  decltype(&ncclGroupEnd) GroupEnd{nullptr};
+  decltype(&ncclGetErrorString) GetErrorString{nullptr};
+  bool ok{false};
+
+  static const Rccl& get()
+  {
+    static const Rccl r = [] {
+      Rccl x;
+      void* lib = nullptr;
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib)
+          break;
+      }
+      if (!lib)
+        return x;
+      auto sym = [&](const char* n) { return dlsym(lib, n); };
+      x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+      x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+      x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
+      x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+      x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+      x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+      x.ok = x.CommInitAll && x.CommDestroy && x.AllGather && x.GroupStart && x.GroupEnd &&
+             x.GetErrorString;
+      return x;
+    }();
+    return r;
+  }
+};
+#define GGNN_RCCL_CHECK(expr)                                                              \
+  do {                                                                                     \
+    ncclResult_t _r = (expr);                                                              \
+    if (_r != ncclSuccess)                                                                 \
+      throw ::ggnn_amd::Error(GGNN_DEVICE_ERROR, std::string(#expr) + ": " +               \
+                                                     Rccl::get().GetErrorString(_r));      \
+  } while (0)
+
 // everything one GPU owns (GPUInstance of the reference, gpu_instance.cuh:60-221, reduced to
 // resident shards)
 struct DeviceCtx {
@@ -155,6 +204,15 @@ struct DeviceCtx {
   float build_ms{0.f}, query_ms{0.f};
   uint64_t n_dist{0}, n_pop{0}, n_float_rows{0}, n_code_rows{0};
   DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
+  // result staging of query(): grown on demand, kept between calls
+  DeviceBuffer r_ids, r_dists;  // this GPU's sorted rows [Nq, K * shards_per_gpu]
+  DeviceBuffer g_ids, g_dists;  // rows of all GPUs after the exchange [G][Nq, K * shards_per_gpu]
+  DeviceBuffer m_ids, m_dists;  // merged slice
+  static void grow(DeviceBuffer& b, size_t bytes)
+  {
+    if (b.bytes < bytes)
+      b.alloc(bytes);
+  }
 
   DeviceCtx() = default;
   DeviceCtx(const DeviceCtx&) = delete;
@@ -170,6 +228,12 @@ struct DeviceCtx {
     o.ev_a = o.ev_b = nullptr;
     base_copy = std::move(o.base_copy);
     bf_rescanned = std::move(o.bf_rescanned);
+    r_ids = std::move(o.r_ids);
+    r_dists = std::move(o.r_dists);
+    g_ids = std::move(o.g_ids);
+    g_dists = std::move(o.g_dists);
+    m_ids = std::move(o.m_ids);
+    m_dists = std::move(o.m_dists);
     d_base = o.d_base;
     first_shard = o.first_shard;
     shards = std::move(o.shards);
@@ -233,6 +297,56 @@ struct ggnn_handle {
 
   std::string last_error;
 
+  // one RCCL communicator per GPU of a multi-GPU handle (created with the first exchange)
+  std::vector<ncclComm_t> comms;
+  int rccl_state{0};  // 0 = not tried, 1 = communicators ready, -1 = unavailable (peer copies)
+  const char* last_exchange{"none"};
+
+  ~ggnn_handle() { destroy_comms(); }
+  void destroy_comms()
+  {
+    if (!comms.empty() && Rccl::get().ok)
+      for (ncclComm_t c : comms)
+        if (c)
+          (void)Rccl::get().CommDestroy(c);
+    comms.clear();
+    rccl_state = 0;
+  }
+  // RCCL needs distinct devices per rank; a handle whose contexts share a device (tests on a
+  // one-GPU box) and builds without librccl exchange through peer copies instead.
+  // GGNN_EXCHANGE=rccl|copy forces one of the two (rccl also for a single GPU: a 1-rank world).
+  bool ensure_comms()
+  {
+    if (rccl_state != 0)
+      return rccl_state > 0;
+    rccl_state = -1;
+    const char* force = std::getenv("GGNN_EXCHANGE");
+    if (force && std::string(force) == "copy")
+      return false;
+    std::vector<int> ids;
+    for (const DeviceCtx& ctx : devs)
+      ids.push_back(ctx.device);
+    std::vector<int> uniq = ids;
+    std::sort(uniq.begin(), uniq.end());
+    if (std::adjacent_find(uniq.begin(), uniq.end()) != uniq.end())
+      return false;
+    if (!Rccl::get().ok) {
+      GGNN_LOG(0, "librccl.so not found: exchanging shard results with peer copies");
+      return false;
+    }
+    comms.assign(ids.size(), nullptr);
+    const ncclResult_t r = Rccl::get().CommInitAll(comms.data(), static_cast<int>(ids.size()),
+                                                   ids.data());
+    if (r != ncclSuccess) {
+      GGNN_LOG(0, "ncclCommInitAll failed (%s): exchanging shard results with peer copies",
+               Rccl::get().GetErrorString(r));
+      comms.clear();
+      return false;
+    }
+    rccl_state = 1;
+    return true;
+  }
+
   size_t row_bytes() const { return static_cast<size_t>(pad_D) * dtype_size(base_dtype); }
   uint32_t num_shards() const { return shards_per_gpu * static_cast<uint32_t>(devs.size()); }
   // every shard of every GPU is built or loaded (a partly loaded handle has no graph)
@@ -254,6 +368,7 @@ struct ggnn_handle {
   void rollback_graph()
   {
     DeviceRestoreGuard keep;
+    destroy_comms();
     devs.clear();
     prepared = false;
     shards_per_gpu = 0;
@@ -724,18 +839,17 @@ struct ggnn_handle {
       return;
     const uint32_t nq = static_cast<uint32_t>(Nq);
     const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
-    std::vector<DeviceBuffer> r_ids(devs.size()), r_dists(devs.size());
+    const size_t part = nq * row;
 
     for_each_device([&](DeviceCtx& ctx) {
-      const size_t i = static_cast<size_t>(&ctx - devs.data());
       Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
       int32_t* d_ids = ids_out;
       float* d_dists = dists_out;
       if (!direct) {
-        r_ids[i].alloc(nq * row * 4);
-        r_dists[i].alloc(nq * row * 4);
-        d_ids = r_ids[i].as<int32_t>();
-        d_dists = r_dists[i].as<float>();
+        DeviceCtx::grow(ctx.r_ids, part * 4);
+        DeviceCtx::grow(ctx.r_dists, part * 4);
+        d_ids = ctx.r_ids.as<int32_t>();
+        d_dists = ctx.r_dists.as<float>();
       }
       query_device(ctx, sq.ptr, nq, k_query, tau_query, max_iterations, measure, d_ids, d_dists);
     });
@@ -749,35 +863,106 @@ struct ggnn_handle {
     if (direct)
       return;
 
-    DeviceCtx& d0 = devs[0];
-    d0.activate();
-    if (devs.size() == 1) {
+    const char* force = std::getenv("GGNN_EXCHANGE");
+    const bool force_rccl = force && std::string(force) == "rccl";
+    if (devs.size() == 1 && !force_rccl) {
       // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, r_ids[0].p, row * 4, k_query * 4ull,
+      DeviceCtx& d0 = devs[0];
+      d0.activate();
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, d0.r_ids.p, row * 4, k_query * 4ull,
                                       nq, hipMemcpyDeviceToHost, d0.stream));
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, r_dists[0].p, row * 4,
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, d0.r_dists.p, row * 4,
                                       k_query * 4ull, nq, hipMemcpyDeviceToHost, d0.stream));
       GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
+      last_exchange = "none";
       return;
     }
-    // several GPUs: candidates to the first GPU (peer copies over xGMI), k-way merge there with
-    // id offset g * shards_per_gpu * N_shard (result_merger.cpp:115-116)
+    if (ensure_comms())
+      exchange_rccl(nq, k_query, row, ids_out, dists_out);
+    else
+      exchange_peer_copies(nq, k_query, row, ids_out, dists_out);
+  }
+
+  // Several GPUs, RCCL: every GPU contributes its sorted rows to ONE grouped all-gather (ids and
+  // distances of all ranks in one ncclGroup, over xGMI), merges a 1/G slice of the queries with
+  // id offset g * shards_per_gpu * N_shard (result_merger.cpp:115-116) and copies that slice to
+  // the caller's arrays.  The reference copies everything to the host and merges there with a
+  // heap per query (ggnn.cu:308-329, result_merger.cpp:51-149).
+  void exchange_rccl(uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out, float* dists_out)
+  {
+    const Rccl& rccl = Rccl::get();
+    const size_t G = devs.size();
     const size_t part = nq * row;
-    DeviceBuffer g_ids(devs.size() * part * 4), g_dists(devs.size() * part * 4), m_ids(nq * k_query * 4ull),
-        m_dists(nq * k_query * 4ull);
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      DeviceCtx::grow(ctx.g_ids, G * part * 4);
+      DeviceCtx::grow(ctx.g_dists, G * part * 4);
+    }
+    GGNN_RCCL_CHECK(rccl.GroupStart());
+    for (size_t g = 0; g < G; ++g) {
+      DeviceCtx& ctx = devs[g];
+      GGNN_RCCL_CHECK(rccl.AllGather(ctx.r_ids.p, ctx.g_ids.p, part, ncclInt32, comms[g], ctx.stream));
+      GGNN_RCCL_CHECK(
+          rccl.AllGather(ctx.r_dists.p, ctx.g_dists.p, part, ncclFloat32, comms[g], ctx.stream));
+    }
+    GGNN_RCCL_CHECK(rccl.GroupEnd());
+    const uint32_t per = (nq + static_cast<uint32_t>(G) - 1) / static_cast<uint32_t>(G);
+    for (size_t g = 0; g < G; ++g) {
+      DeviceCtx& ctx = devs[g];
+      const uint32_t first = std::min<uint32_t>(nq, static_cast<uint32_t>(g) * per);
+      const uint32_t count = std::min<uint32_t>(per, nq - first);
+      if (!count)
+        continue;
+      ctx.activate();
+      DeviceCtx::grow(ctx.m_ids, static_cast<size_t>(nq) * k_query * 4);
+      DeviceCtx::grow(ctx.m_dists, static_cast<size_t>(nq) * k_query * 4);
+      launch_merge_results_range(nq, k_query, static_cast<uint32_t>(G), static_cast<uint32_t>(row),
+                                 shards_per_gpu * cfg.N, ctx.g_ids.as<int32_t>(),
+                                 ctx.g_dists.as<float>(), ctx.m_ids.as<int32_t>(),
+                                 ctx.m_dists.as<float>(), nullptr, nullptr, first, count, ctx.stream);
+      const size_t off = static_cast<size_t>(first) * k_query;
+      GGNN_HIP_CHECK(hipMemcpyAsync(ids_out + off, ctx.m_ids.as<int32_t>() + off,
+                                    static_cast<size_t>(count) * k_query * 4,
+                                    hipMemcpyDeviceToHost, ctx.stream));
+      GGNN_HIP_CHECK(hipMemcpyAsync(dists_out + off, ctx.m_dists.as<float>() + off,
+                                    static_cast<size_t>(count) * k_query * 4,
+                                    hipMemcpyDeviceToHost, ctx.stream));
+    }
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    }
+    last_exchange = "rccl";
+  }
+
+  // Several contexts without RCCL (contexts sharing one device, or no librccl): candidates to the
+  // first GPU with peer copies, k-way merge there.
+  void exchange_peer_copies(uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                            float* dists_out)
+  {
+    DeviceCtx& d0 = devs[0];
+    d0.activate();
+    const size_t part = nq * row;
+    DeviceCtx::grow(d0.g_ids, devs.size() * part * 4);
+    DeviceCtx::grow(d0.g_dists, devs.size() * part * 4);
+    DeviceCtx::grow(d0.m_ids, static_cast<size_t>(nq) * k_query * 4);
+    DeviceCtx::grow(d0.m_dists, static_cast<size_t>(nq) * k_query * 4);
     for (size_t g = 0; g < devs.size(); ++g) {
-      GGNN_HIP_CHECK(hipMemcpyAsync(g_ids.as<int32_t>() + g * part, r_ids[g].p, part * 4,
+      GGNN_HIP_CHECK(hipMemcpyAsync(d0.g_ids.as<int32_t>() + g * part, devs[g].r_ids.p, part * 4,
                                     hipMemcpyDefault, d0.stream));
-      GGNN_HIP_CHECK(hipMemcpyAsync(g_dists.as<float>() + g * part, r_dists[g].p, part * 4,
+      GGNN_HIP_CHECK(hipMemcpyAsync(d0.g_dists.as<float>() + g * part, devs[g].r_dists.p, part * 4,
                                     hipMemcpyDefault, d0.stream));
     }
     launch_merge_results(nq, k_query, static_cast<uint32_t>(devs.size()),
-                         static_cast<uint32_t>(row), shards_per_gpu * cfg.N, g_ids.as<int32_t>(),
-                         g_dists.as<float>(), m_ids.as<int32_t>(), m_dists.as<float>(), d0.stream);
-    GGNN_HIP_CHECK(hipMemcpyAsync(ids_out, m_ids.p, m_ids.bytes, hipMemcpyDeviceToHost, d0.stream));
-    GGNN_HIP_CHECK(
-        hipMemcpyAsync(dists_out, m_dists.p, m_dists.bytes, hipMemcpyDeviceToHost, d0.stream));
+                         static_cast<uint32_t>(row), shards_per_gpu * cfg.N, d0.g_ids.as<int32_t>(),
+                         d0.g_dists.as<float>(), d0.m_ids.as<int32_t>(), d0.m_dists.as<float>(),
+                         d0.stream);
+    GGNN_HIP_CHECK(hipMemcpyAsync(ids_out, d0.m_ids.p, static_cast<size_t>(nq) * k_query * 4,
+                                  hipMemcpyDeviceToHost, d0.stream));
+    GGNN_HIP_CHECK(hipMemcpyAsync(dists_out, d0.m_dists.p, static_cast<size_t>(nq) * k_query * 4,
+                                  hipMemcpyDeviceToHost, d0.stream));
     GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
+    last_exchange = "copy";
   }
 
   // GGNNImpl::bfQueryImpl, ggnn.cu:332-390
@@ -1181,6 +1366,11 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
   if (bf_ms)
     *bf_ms = h->bf_ms;
   return GGNN_OK;
+}
+
+const char* ggnn_last_exchange(const ggnn_t* h)
+{
+  return h ? h->last_exchange : "none";
 }
 
 ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned)

@@ -70,11 +70,15 @@ void launch_sort_shard_results(uint32_t Nq, uint32_t row_len, int32_t* ids, floa
 __global__ void merge_results_kernel(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
                                      uint32_t id_offset_per_part, const int32_t* parts_ids,
                                      const float* parts_dists, int32_t* ids_out, float* dists_out,
-                                     const uint32_t* qlist, const uint32_t* qcount)
+                                     const uint32_t* qlist, const uint32_t* qcount,
+                                     uint32_t first, uint32_t count)
 {
+  // queries [first, first + count) of the Nq rows per part (or the listed ones); the outputs are
+  // indexed by the query number as well
   uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= Nq)
+  if (n >= count)
     return;
+  n += first;
   if (qlist) {
     if (n >= *qcount)
       return;
@@ -127,16 +131,26 @@ void launch_merge_results_subset(uint32_t Nq, uint32_t k, uint32_t num_parts, ui
                                  const uint32_t* qlist, const uint32_t* qcount,
                                  hipStream_t stream)
 {
-  if (!Nq)
+  launch_merge_results_range(Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists,
+                             ids_out, dists_out, qlist, qcount, 0, Nq, stream);
+}
+
+void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
+                                uint32_t id_offset_per_part, const int32_t* parts_ids,
+                                const float* parts_dists, int32_t* ids_out, float* dists_out,
+                                const uint32_t* qlist, const uint32_t* qcount, uint32_t first,
+                                uint32_t count, hipStream_t stream)
+{
+  if (!Nq || !count)
     return;
   GGNN_REQUIRE(num_parts >= 1 && num_parts <= 64, GGNN_INVALID_ARGUMENT,
                "number of parts must be in [1, 64]");
   GGNN_REQUIRE(static_cast<uint64_t>(num_parts) * stride >= k, GGNN_INVALID_ARGUMENT,
                "not enough candidates to merge");
   const uint32_t block = 128;
-  hipLaunchKernelGGL(merge_results_kernel, dim3((Nq + block - 1) / block), dim3(block), 0, stream,
-                     Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists, ids_out,
-                     dists_out, qlist, qcount);
+  hipLaunchKernelGGL(merge_results_kernel, dim3((count + block - 1) / block), dim3(block), 0,
+                     stream, Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists,
+                     ids_out, dists_out, qlist, qcount, first, count);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 

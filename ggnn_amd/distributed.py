@@ -70,6 +70,12 @@ class ShardedGGNN:
         self.n_local = int(t.shape[0])
         self.engine.set_base(t)
 
+    def set_shard_size(self, n_shard):
+        """several resident shards per rank (GGNN::setShardSize on the rank's slice): the local
+        candidates are then sorted rows of K * shards_per_rank entries, merged across ranks with
+        id offset rank * n_local as before"""
+        self.engine.set_shard_size(n_shard)
+
     def build(self, k_build, tau_build, refinement_iterations=2,
               measure=DistanceMeasure.Euclidean):
         self.engine.build(k_build, tau_build, refinement_iterations, measure)

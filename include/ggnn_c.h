@@ -128,6 +128,11 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
 /* per-query work counters of the last ggnn_query (sum over queries and shards): number of
  * distance evaluations and of successful pops; used for the roofline figure. */
 ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop);
+/* how the last ggnn_query combined the per-GPU results (replaces the D2H + CPU heap merge of
+ * ggnn.cu:308-329 / result_merger.cpp:51-149): "none" (one GPU), "rccl" (grouped ncclAllGather
+ * over xGMI + per-GPU slice merge) or "copy" (peer copies to the first GPU: contexts sharing one
+ * device, or no librccl).  Environment GGNN_EXCHANGE=rccl|copy forces one of them. */
+const char* ggnn_last_exchange(const ggnn_t* h);
 /* queries of the last ggnn_bf_query that were answered by the exhaustive scan because the
  * matrix-core pre-selection could not be certified exact (tracing; results are exact either way) */
 ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned);

@@ -222,6 +222,57 @@ def test_duplicate_points_zero_distances(orc):
     assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
 
 
+def test_rccl_exchange_single_rank_world(orc, monkeypatch):
+    """GGNN_EXCHANGE=rccl routes even a one-GPU handle through the RCCL exchange of the multi-GPU
+    path (ncclCommInitAll over the handle's devices, grouped ncclAllGather of ids and distances,
+    slice merge on the device, slice copies to the host): a one-rank world on this one-GPU box, the
+    same code the 8-GPU handle runs.  Results must equal the plain path's."""
+    import ggnn_amd as ggnn
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 187), make_int_data(333, D, 188)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_shard_size(2000)       # 4 resident shards: rows of K * 4 sorted candidates
+    eng.build(24, 0.5, 1)
+    ids, d = eng.query(q, K, 0.7, 200)
+    assert eng.last_exchange() == "none"
+    monkeypatch.setenv("GGNN_EXCHANGE", "rccl")
+    ids2, d2 = eng.query(q, K, 0.7, 200)
+    assert eng.last_exchange() == "rccl"
+    assert torch.equal(ids, ids2) and torch.equal(d, d2)
+    ids3, d3 = eng.query(q[:1], K, 0.7, 200)   # fewer queries than ranks * anything: slice math
+    assert torch.equal(ids[:1], ids3) and torch.equal(d[:1], d3)
+
+
+def test_failed_load_rolls_back(tmp_path):
+    """a load() that fails half way must not leave a handle that claims a graph."""
+    import ggnn_amd as ggnn
+    base, q = make_int_data(4000, 32, 191), make_int_data(16, 32, 192)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_working_directory(str(tmp_path))
+    eng.set_shard_size(2000)
+    eng.build(24, 0.5, 1)
+    eng.store()
+    ref_ids, ref_d = eng.query(q, 10, 0.6, 200)
+    os.remove(os.path.join(str(tmp_path), "part_1.ggnn"))
+    eng2 = ggnn.GGNN()
+    eng2.set_base(base)
+    eng2.set_working_directory(str(tmp_path))
+    eng2.set_shard_size(2000)
+    with pytest.raises(RuntimeError, match="missing or mismatching graph file"):
+        eng2.load(24)
+    with pytest.raises(RuntimeError, match="no graph to query"):
+        eng2.query(q, 10, 0.6, 200)
+    with pytest.raises(RuntimeError, match="No graph has been built"):
+        eng2.get_graph(0)
+    eng2.set_base(base)            # allowed again: the handle is back in its set_base state
+    eng2.set_shard_size(2000)
+    eng2.build(24, 0.5, 1)         # and a build succeeds
+    ids, d = eng2.query(q, 10, 0.6, 200)
+    assert tuple(ids.shape) == (16, 10)
+
+
 @pytest.mark.parametrize("shard_size", [4000, 2000])
 def test_in_process_multi_gpu(orc, shard_size):
     """set_gpus([...]) with several entries drives several device contexts from one handle (host
@@ -258,6 +309,7 @@ def test_in_process_multi_gpu(orc, shard_size):
         parts_i.append(si)
         parts_d.append(sd)
     r_ids, r_d = orc.merge_results(parts_i, parts_d, K, spg, n_shard)
+    assert eng.last_exchange() == "copy"   # both contexts share device 0: RCCL needs distinct GPUs
     assert np.array_equal(d.numpy(), r_d)
     uniq = np.ones_like(r_d, bool)
     uniq[:, 1:] &= r_d[:, 1:] != r_d[:, :-1]
