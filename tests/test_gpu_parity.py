@@ -427,9 +427,10 @@ def _mini_graph(orc, dtype, D, K, measure):
     return _graph_cache[key]
 
 
+# ("f32", 960, 24, 1) is BASELINE configs[2] (GIST1M shape: cosine AND 960 dimensions together)
 CONFIGS = [("u8", 128, 24, 0), ("f32", 96, 24, 0), ("f32", 256, 24, 0), ("f32", 960, 24, 0),
            ("u8", 960, 24, 0), ("f32", 128, 40, 0), ("f32", 64, 60, 0), ("f32", 128, 24, 1),
-           ("f32", 32, 8, 0)]
+           ("f32", 32, 8, 0), ("f32", 960, 24, 1)]
 
 
 @pytest.mark.parametrize("dtype,D,K,measure", CONFIGS)
@@ -479,7 +480,8 @@ def test_config_matrix_query_top_merge(ops, orc, dtype, D, K, measure):
 
 @pytest.mark.parametrize("dtype,D,K,measure", [("u8", 128, 24, 0), ("f32", 960, 24, 0),
                                                ("f32", 64, 60, 0), ("f32", 96, 24, 0),
-                                               ("f32", 128, 24, 1), ("u8", 128, 24, 1)])
+                                               ("f32", 128, 24, 1), ("u8", 128, 24, 1),
+                                               ("f32", 960, 24, 1)])
 def test_config_matrix_sym(ops, orc, dtype, D, K, measure):
     g = _mini_graph(orc, dtype, D, K, measure)
     c = g["cfg"]
@@ -816,7 +818,8 @@ def test_prescreen_cosine_bound_never_exceeds_the_float_distance(ops, maker, D):
     assert rej.float().mean().item() > 0.9
 
 
-@pytest.mark.parametrize("maker,D", [(_clustered, 128), (make_int_data, 128), (_clustered, 320)])
+@pytest.mark.parametrize("maker,D", [(_clustered, 128), (make_int_data, 128), (_clustered, 320),
+                                     (_clustered, 960)])
 def test_query_and_merge_prescreened_cosine_equal_plain(ops, orc, maker, D):
     N, K = 2500, 24
     base, q = maker(N, D, 111), maker(150, D, 112)
