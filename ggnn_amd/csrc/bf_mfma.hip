@@ -55,6 +55,7 @@ struct BfMfmaArgs {
   int32_t* part_ids;   // [slices][Nq][KP]
   float* part_dists;   // [slices][Nq][KP]
   uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
+  uint32_t DM;  // floats of the shift vector kept in LDS by the chunked kernel (D rounded up)
 };
 
 // ---- 1. squared norms ---------------------------------------------------------------------------
@@ -107,6 +108,20 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
       vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if ((threadIdx.x & 63) == 0)
       atomicMax(max_out, __float_as_uint(vmax));
+  }
+}
+
+// out = fl(in - mean), row by row: the query set is shifted once, up front (it is small), so that
+// the tile kernels load their A operand without touching the mean
+__global__ void __launch_bounds__(256) shift_rows_kernel(const float* in, uint64_t n4, uint32_t D,
+                                                        const float* mean, float* out)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4;
+       i += static_cast<uint64_t>(gridDim.x) * 256) {
+    const uint32_t col = static_cast<uint32_t>((i * 4) % D);
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    const float4 m = *reinterpret_cast<const float4*>(mean + col);
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w);
   }
 }
 
@@ -164,7 +179,8 @@ struct TileStage;
 template <>
 struct TileStage<float> {
   float4 r[4];
-  float4 mu[4];  // shift of this thread's columns (zero without centring)
+  float4 mu[4];  // shift of this thread's columns (single-chunk kernel; zero without centring)
+  uint32_t vmask;  // bit e: r[e] holds row data (chunked kernel: the shift comes from LDS)
   float bn;  // threads 0..31: squared norm of tile row threadIdx.x (pad value past the end)
   // columns [col0, col0 + CW) are staged next; the single-chunk kernel calls this once
   GGNN_DEV void set_mean(const float* mean, uint32_t D, uint32_t col0, uint32_t CW)
@@ -185,13 +201,39 @@ struct TileStage<float> {
     if (threadIdx.x < (uint32_t)kBfTileRows && row0 + threadIdx.x < end)
       bn = bnorm[row0 + threadIdx.x];
     const uint32_t cpr = CW / 4;
+    vmask = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, col = col0 + 4 * (idx % cpr);
+      // (predicated load on purpose: the clamped-address + select form measured 30 % slower)
       r[e] = mu[e];  // rows / columns past the end stage as zero after the shift
-      if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D)
+      if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D) {
         r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + col);
+        vmask |= 1u << e;
+      }
+    }
+  }
+  // chunked kernel: the shift of columns [col0, col0 + CW) is read from the mean vector in LDS
+  // (a global load here would sit on the critical path of every staged tile)
+  GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float* mean_lds,
+                              uint32_t col0) const
+  {
+    if (threadIdx.x < (uint32_t)kBfTileRows)
+      tile[threadIdx.x * DP + CW] = bn;
+    const uint32_t cpr = CW / 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t idx = threadIdx.x + 256 * e;
+      const uint32_t row = idx / cpr, c4 = idx % cpr;
+      if (row < (uint32_t)kBfTileRows) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vmask & (1u << e)) {
+          const float4 m = *reinterpret_cast<const float4*>(mean_lds + col0 + 4 * c4);
+          v = make_float4(r[e].x - m.x, r[e].y - m.y, r[e].z - m.z, r[e].w - m.w);
+        }
+        *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) = v;
+      }
     }
   }
   GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
@@ -216,6 +258,10 @@ struct TileStage<uint8_t> {
   uint4 r;
   float bn;
   GGNN_DEV void set_mean(const float*, uint32_t, uint32_t, uint32_t) {}  // bytes are not shifted
+  GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float*, uint32_t) const
+  {
+    store(tile, DP, CW);
+  }
   GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
                      uint32_t CW, const float* bnorm, float bn_pad)
   {
@@ -250,27 +296,42 @@ struct TileStage<uint8_t> {
 };
 
 // A operand of one chunk: aq[kk] = q[col0 + h*Dh + kk] (0 outside the row / the query set)
+// (float32 squared L2: `query` is the shifted copy made by shift_rows_kernel)
+// (predicated on purpose: with unconditional loads the scheduler hoists all sixteen pieces of the
+// next chunk to the top of the chain and spills 55 registers at two waves per SIMD)
+GGNN_DEV float4 load_query_piece(const float* qrow, bool qvalid, uint32_t D, uint32_t Dh,
+                                 uint32_t col_h, int t)
+{
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (qvalid && static_cast<uint32_t>(4 * t) < Dh && col_h + 4 * t < D)
+    v = *reinterpret_cast<const float4*>(qrow + col_h + 4 * t);
+  return v;
+}
 GGNN_DEV void load_query_chunk(float (&aq)[64], const float* qrow, bool qvalid, uint32_t D,
-                               uint32_t Dh, uint32_t col_h, const float* mean)
+                               uint32_t Dh, uint32_t col_h)
 {
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qvalid && static_cast<uint32_t>(4 * t) < Dh && col_h + 4 * t < D) {
-      v = *reinterpret_cast<const float4*>(qrow + col_h + 4 * t);
-      if (mean) {
-        const float4 m = *reinterpret_cast<const float4*>(mean + col_h + 4 * t);
-        v = make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w);
-      }
-    }
+    const float4 v = load_query_piece(qrow, qvalid, D, Dh, col_h, t);
     aq[4 * t + 0] = v.x;
     aq[4 * t + 1] = v.y;
     aq[4 * t + 2] = v.z;
     aq[4 * t + 3] = v.w;
   }
 }
+// piece t (4 operands) of a uint8 query chunk: bytes [4t, 4t+4) of the lane's half row
+GGNN_DEV float4 load_query_piece(const uint8_t* qrow, bool qvalid, uint32_t D, uint32_t Dh,
+                                 uint32_t col_h, int t)
+{
+  const uint32_t col = col_h + 4 * t;
+  const bool ok = qvalid && static_cast<uint32_t>(4 * t) < Dh && col < D;
+  uint32_t w = *reinterpret_cast<const uint32_t*>(qrow + min(col, D - 4));
+  w = ok ? w : 0u;
+  return make_float4(static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu),
+                     static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24));
+}
 GGNN_DEV void load_query_chunk(float (&aq)[64], const uint8_t* qrow, bool qvalid, uint32_t D,
-                               uint32_t Dh, uint32_t col_h, const float*)
+                               uint32_t Dh, uint32_t col_h)
 {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -337,6 +398,30 @@ GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t r
   }
 }
 
+// 4*NU MFMA steps of one (tile, chunk) pair: acc += aq x B with B read from the LDS tile row bt.
+// PREFETCH: every group of four query operands is reloaded for the next chunk (columns from
+// next_col on) right after its MFMAs have been issued.
+template <int NU, bool PREFETCH, typename BaseT>
+GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt, const BaseT* qrow,
+                         bool qvalid, uint32_t D, uint32_t Dh, uint32_t next_col)
+{
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc, 0, 0, 0);
+    if (PREFETCH) {
+      const float4 nq = load_query_piece(qrow, qvalid, D, Dh, next_col, u);
+      aq[4 * u + 0] = nq.x;
+      aq[4 * u + 1] = nq.y;
+      aq[4 * u + 2] = nq.z;
+      aq[4 * u + 3] = nq.w;
+    }
+  }
+}
+
 // distance of one accumulator entry (expanded form; invalid base rows give +inf)
 template <int MODE>
 GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
@@ -354,7 +439,8 @@ GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
 // MFMA chain of a tile in ONE basic block so that the LDS reads of the B operand are scheduled
 // ahead of the MFMAs that consume them.
 template <typename BaseT, int MODE, int T, int NU>
-__global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(T == 2 ? 2 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   // the two tile buffers are addressed as lds_f + offset (never through a pointer array: a select
@@ -386,29 +472,36 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
   const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
   float aq[64];
   // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
-  float qn[16];
+  // single-chunk path: query norms and thr[r], the worst entry of the candidate list of query row
+  // i(r), stay in registers (nothing beats -inf: padding); the chunked path fetches them per group
+  float qn[16], thr[16];
+  if constexpr (T == 1) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-    qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
-  }
-
-  // thr[r]: worst entry of the candidate list of query row i(r); nothing beats -inf (padding)
-  float thr[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-    thr[r] = qi < a.Nq ? inf_f() : -inf_f();
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+      qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
+      thr[r] = qi < a.Nq ? inf_f() : -inf_f();
+    }
   }
 
   // squared norm standing in for rows past the end of the slice: +inf distance for L2
   const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
   TileStage<BaseT> stage;
-  stage.set_mean(a.mean, a.D, 0, CW);
+  stage.set_mean(T == 1 ? a.mean : nullptr, a.D, 0, CW);
+  // chunked kernel: the whole shift vector sits behind the candidate lists in LDS
+  float* mean_lds = reinterpret_cast<float*>(list_id + kBfQueriesPerBlock * a.KP);
+  if constexpr (T > 1) {
+    for (uint32_t i = tid; i < a.DM; i += 256)
+      mean_lds[i] = (a.mean && i < a.D) ? a.mean[i] : 0.f;
+    __syncthreads();
+  }
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
     stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
-    stage.store(lds_f, a.DP, CW);
+    if constexpr (T > 1)
+      stage.store_shifted(lds_f, a.DP, CW, mean_lds, 0);
+    else
+      stage.store(lds_f, a.DP, CW);
   }
   __syncthreads();
 
@@ -417,7 +510,7 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
     // of tile t -- its 16 x (add, fma, compare) are independent of the running accumulator, so
     // the matrix pipe does not drain between tiles.  Before the first tile the "previous"
     // accumulator is a dummy whose distances are +inf.
-    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh, a.mean);
+    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
     f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bn_prev = bn_pad;
     bool jvalid_prev = false;
@@ -484,8 +577,11 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
       acc[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (uint32_t c = 0; c < nch; ++c) {
-      if (nch > 1 || g0 == 0)
-        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, c * CW + h * a.Dh, a.mean);
+      // the query chunk of (g0, c) was loaded during the last tile of the previous (group, chunk)
+      // -- see below -- except for the very first one
+      if (g0 == 0 && c == 0)
+        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
+      const uint32_t next_col = ((c + 1 < nch) ? (c + 1) * CW : 0u) + h * a.Dh;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t tt = g0 + t;
@@ -493,8 +589,9 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           break;  // uniform
         // the pair after this one: next tile of the group, else next chunk, else next group
         bool has_next = true;
+        const bool last_of_chunk = !(t + 1 < T && tt + 1 < ntiles);
         uint32_t n_tile = tt + 1, n_chunk = c;
-        if (!(t + 1 < T && tt + 1 < ntiles)) {
+        if (last_of_chunk) {
           if (c + 1 < nch) {
             n_tile = g0;
             n_chunk = c + 1;
@@ -506,27 +603,24 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
           else
             has_next = false;
         }
-        if (has_next) {
-          if (nch > 1)
-            stage.set_mean(a.mean, a.D, n_chunk * CW, CW);
+        if (has_next)
           stage.load(base, a.D, begin + n_tile * kBfTileRows, end, n_chunk * CW, CW, a.bnorm,
                      bn_pad);
-        }
 
-        // S += Q_chunk x B_chunk^T for this wave's 32 queries against the 32 tile rows
+        // S += Q_chunk x B_chunk^T for this wave's 32 queries against the 32 tile rows.  During
+        // the last tile of a chunk every group of four query operands is reloaded for the NEXT
+        // chunk as soon as its MFMAs have been issued: the loads travel while the rest of the
+        // chain runs, instead of stalling the first MFMA of the next chunk.
         const float* bt = lds_f + (p & 1) * tile_floats + j * a.DP + h * a.Dh;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          if (u < NU) {  // Dh = 4*NU = 64 on this path
-            const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc[t], 0, 0, 0);
-          }
-        }
+        // two copies of the chain, the branch outside: each is ONE basic block, so the LDS reads
+        // of the B operand are scheduled ahead of the MFMAs that consume them
+        if (last_of_chunk)
+          mfma_chain<NU, true>(acc[t], aq, bt, qrow, qvalid, a.D, a.Dh, next_col);
+        else
+          mfma_chain<NU, false>(acc[t], aq, bt, qrow, qvalid, a.D, a.Dh, next_col);
         if (has_next)
-          stage.store(lds_f + ((p + 1) & 1) * tile_floats, a.DP, CW);
+          stage.store_shifted(lds_f + ((p + 1) & 1) * tile_floats, a.DP, CW, mean_lds,
+                              n_chunk * CW);
         __syncthreads();
         ++p;
       }
@@ -535,6 +629,16 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
     // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows.  The
     // thresholds (worst list entry of each of the lane's query rows) live in registers and change
     // only after an insertion, so the common case is 16 x (add, fma, compare) and one branch.
+    // (thresholds and query norms are fetched here, not held across the MFMA loop: 32 registers
+    // less, which is what lets a second workgroup share the CU)
+    float* wave_d2 = list_d + wave * 32 * KP;
+    float thr2[16], qn2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t ql = (r & 3) + 8 * (r >> 2) + 4 * h;
+      thr2[r] = wave_d2[ql * KP + KP - 1];   // -inf for padding queries (list initialisation)
+      qn2[r] = qbase + ql < a.Nq ? a.qnorm[qbase + ql] : 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const uint32_t tt = g0 + t;
@@ -548,12 +652,12 @@ __global__ void __launch_bounds__(256) bf_mfma_kernel(const BfMfmaArgs a)
       unsigned long long any = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        dd[r] = bf_expand<MODE>(acc[t][r], qn[r], bn, jvalid);
-        any |= __ballot(dd[r] < thr[r]);
+        dd[r] = bf_expand<MODE>(acc[t][r], qn2[r], bn, jvalid);
+        any |= __ballot(dd[r] < thr2[r]);
       }
       if (!any)
         continue;
-      bf_insert_hits(dd, thr, row0, list_d + wave * 32 * KP, list_id + wave * 32 * KP, KP, h);
+      bf_insert_hits(dd, thr2, row0, wave_d2, list_id + wave * 32 * KP, KP, h);
     }
   }
   }  // T > 1
@@ -830,7 +934,13 @@ __global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
 bool bf_mfma_supported(const BfLaunch& a)
 {
   const uint32_t epc = a.dtype == GGNN_F32 ? 4 : 16;
-  return a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 && a.N_base >= 4096;
+  if (!(a.D % epc == 0 && a.k_query + 8 <= kBfMaxKP && a.Nq >= 256 && a.N_base >= 4096))
+    return false;
+  // tiles + candidate lists (+ the shift vector of the chunked kernel) must fit into 160 KB of LDS
+  const size_t lists = 2ull * kBfQueriesPerBlock * (a.k_query + 8);
+  const size_t tiles = 2ull * kBfTileRows * 132;
+  const size_t shift = a.D > 128 ? (a.D + 3) / 4 * 4 : 0;
+  return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
 // freed blocks stay in the device's pool instead of going back to the driver at the next
@@ -897,7 +1007,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_mean = (static_cast<size_t>(a.D) + 3) / 4 * 4;
   const size_t n_partial = center ? static_cast<size_t>(kBfMeanBlocks) * n_mean : 0;
   const size_t n_list = (static_cast<size_t>(a.Nq) + 3) / 4 * 4;
-  const size_t words = n_norms + n_mean + n_partial + 4 + n_list + 2 * parts + 2 * rescan_entries;
+  const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
+  const size_t words =
+      n_norms + n_mean + n_partial + 4 + n_list + 2 * parts + 2 * rescan_entries + n_qshift;
   float* scratch = nullptr;
   GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), words * 4, stream));
   float* bnorm = scratch;
@@ -910,6 +1022,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   float* part_dists = reinterpret_cast<float*>(part_ids + parts);
   int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + parts);
   float* rescan_dists = reinterpret_cast<float*>(rescan_ids + rescan_entries);
+  float* q_shifted = rescan_dists + rescan_entries;  // 16-byte aligned: every block above is
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
 
   if (center) {
@@ -920,12 +1033,19 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                        static_cast<const float*>(a.base), a.N_base, a.D, stride, rows, partial);
     hipLaunchKernelGGL(col_mean_final_kernel, dim3((a.D + 255) / 256), dim3(256), 0, stream, partial,
                        a.D, rows, mean);
+    const uint64_t n4 = static_cast<uint64_t>(a.Nq) * a.D / 4;
+    hipLaunchKernelGGL(shift_rows_kernel,
+                       dim3(static_cast<uint32_t>(std::min<uint64_t>((n4 + 255) / 256, 4096))),
+                       dim3(256), 0, stream, static_cast<const float*>(a.query), n4, a.D, mean,
+                       q_shifted);
   }
   const float* d_mean = center ? mean : nullptr;
+  // what the tile and norm kernels see as the query set (the re-rank works on the original rows)
+  const void* tile_query = center ? static_cast<const void*>(q_shifted) : a.query;
 
   BfMfmaArgs m{};
   m.base = a.base;
-  m.query = a.query;
+  m.query = tile_query;
   m.mean = d_mean;
   m.bnorm = bnorm;
   m.qnorm = qnorm;
@@ -939,8 +1059,13 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   m.KP = KP;
   m.slices = slices;
   m.rows_per_slice = rows_per_slice;
-  const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP) * sizeof(float);
+  m.DM = a.D > 128 ? (a.D + 3) / 4 * 4 : 0;  // the chunked kernel keeps the shift vector in LDS
+  const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
+  // rows longer than one chunk: base tiles per accumulator group (GGNN_BF_TILES=2|4 tuning hook)
+  int tiles_per_group = 2;
+  if (const char* e = std::getenv("GGNN_BF_TILES"))
+    tiles_per_group = std::atoi(e) == 4 ? 4 : 2;
 
   BfRerankArgs rr{};
   rr.base = a.base;
@@ -967,9 +1092,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL((row_norms_kernel<T>), dim3(norm_grid(a.N_base)), dim3(256), 0, stream,   \
                        static_cast<const T*>(a.base), a.N_base, a.D, d_mean, bnorm, flags);       \
     hipLaunchKernelGGL((row_norms_kernel<T>), dim3(norm_grid(a.Nq)), dim3(256), 0, stream,       \
-                       static_cast<const T*>(a.query), a.Nq, a.D, d_mean, qnorm,                  \
-                       static_cast<uint32_t*>(nullptr));                                          \
-    const void* kern = (a.D > 128) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>)   \
+                       static_cast<const T*>(tile_query), a.Nq, a.D,                              \
+                       static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr)); \
+    const void* kern = (a.D > 128) ? (tiles_per_group == 2                                             \
+                           ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 2, 16>)      \
+                           : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>))     \
                        : (Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8>)  \
                        : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12>) \
                                     : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 16>);\
