@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libggnn_amd.so")
+# GGNN_AMD_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("GGNN_AMD_LIB") or os.path.join(_HERE, "csrc", "libggnn_amd.so")
 
 OK, INVALID_ARGUMENT, INVALID_STATE, OUT_OF_RANGE, OUT_OF_MEMORY, DEVICE_ERROR, UNSUPPORTED, \
     IO_ERROR = range(8)

@@ -1,95 +1,136 @@
-"""Condense rocprofv3 CSV output (gpurun_out/) into the tracked summaries under profiles/."""
+"""Condense rocprofv3 CSV output (gpurun_out/<tag>/) into the tracked summaries under profiles/."""
 import collections, csv, json, os, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/{tag}"
 out_dir = "profiles"
 os.makedirs(out_dir, exist_ok=True)
+CMD = "python bench.py --lean"
 
-stats = list(csv.DictReader(open(f"{src}/prof_{tag}/bench_kernel_stats.csv")))
+
+def counters(name):
+    path = f"{src}/pmc_{name}/bench_counter_collection.csv"
+    if not os.path.exists(path):
+        return []
+    return list(csv.DictReader(open(path)))
+
+
+workload = None
+try:
+    bench = json.load(open(f"{src}/bench_prof.json"))
+    workload = bench["config"]["workload"]
+    json.dump(bench, open(f"{out_dir}/{tag}_bench_n1_profiled.json", "w"), indent=1)
+except Exception as e:
+    print("no bench line:", e)
+
+stats = list(csv.DictReader(open(f"{src}/prof/bench_kernel_stats.csv")))
 with open(f"{out_dir}/{tag}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 "
-            "--warmup 3 --no-cpu-baseline   (MI355X, 1 GPU)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {CMD} --steps 20 "
+            "--warmup 3   (MI355X, 1 GPU)\n")
     w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
     w.writeheader()
     for r in stats:
         if float(r["Percentage"]) >= 0.001:
             w.writerow(r)
 
+# ---- HBM-side traffic -----------------------------------------------------------------------
 pmc = {}
-for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    path = f"{src}/{name}_{tag}/bench_counter_collection.csv"
-    if not os.path.exists(path):
-        continue
+for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    for r in counters(name):
         if r["Counter_Name"] == counter and "ggnn_amd" in r["Kernel_Name"]:
             agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter] = {"launches": len(v), "avg_kb": sum(v) / len(v),
                                           "last_kb": v[-1], "max_kb": max(v)}
-workload = None
-try:
-    workload = json.load(open(f"{src}/bench_prof.json"))["config"]["workload"]
-except Exception:
-    pass
-json.dump({"workload": workload, "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- "
-                      "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one pass per counter)",
+json.dump({"workload": workload,
+           "command": f"rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- {CMD} "
+                      "--steps 3 --warmup 1 (one pass per counter)",
            "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 64 B per "
                     "128 B request for 16 B/lane loads -> multiply by 2 (MI355X_MICROARCH.md, HBM)",
            "kernels": pmc}, open(f"{out_dir}/{tag}_pmc_hbm.json", "w"), indent=1)
 
-# SQ counters of the query kernels (instruction mix, VALU utilisation)
-sq = {}
-for name in ("pmc_sq1", "pmc_sq2"):
-    path = f"{src}/{name}_{tag}/bench_counter_collection.csv"
-    if not os.path.exists(path):
-        continue
+
+def per_kernel(names, want):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"]
-        if "query_kernel" in k and "bf_" not in k:
-            agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, c in agg.items():
-        for cn, v in c.items():
-            sq.setdefault(k, {})[cn] = sum(v) / len(v)
+    for n in names:
+        for r in counters(n):
+            k = r["Kernel_Name"]
+            if want(k):
+                agg[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {cn: sum(v) / len(v) for cn, v in c.items()} for k, c in agg.items()}
+
+
+is_query = lambda k: "query_kernel" in k and "bf_" not in k
+is_trav = lambda k: any(t in k for t in ("query_kernel", "merge_kernel", "sym_kernel")) and "bf_" not in k
+
+# ---- SQ counters of the query kernels (instruction mix, VALU utilisation) -----------------------
+sq = per_kernel(("sq1", "sq2"), is_query)
 if sq:
     json.dump({"workload": workload,
-               "command": "rocprofv3 --pmc <SQ counters> --output-format csv -- python bench.py "
-                          "--steps 3 --warmup 1 --no-cpu-baseline (two passes)",
+               "command": f"rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- {CMD} "
+                          "--steps 3 --warmup 1 (two passes)",
                "units": "per launch, summed over the device; SQ cycle counters tick once per 4 "
                         "clocks, so VALU utilisation = SQ_ACTIVE_INST_VALU / (kernel time x "
                         "clock / 4 x 1024 SIMDs)",
                "kernels": sq}, open(f"{out_dir}/{tag}_pmc_sq.json", "w"), indent=1)
 
-# MFMA counters of the brute-force kernel
-path = f"{src}/pmc_mfma_{tag}/bench_counter_collection.csv"
-if os.path.exists(path):
-    c = collections.defaultdict(list)
-    dur = []
-    for r in csv.DictReader(open(path)):
-        if "bf_mfma_kernel" in r["Kernel_Name"]:
-            c[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
-    if c:
-        cnt = {k: sum(v) / len(v) for k, v in c.items()}
-        d = sum(dur) / len(dur)
-        busy = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-        json.dump({"command": "rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
-                              "SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -- "
-                              "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-                   "kernel": "bf_mfma_kernel<float, L2, T=1, NU=16> (10 000 x 1 000 000 x 128 f32, k=10)",
-                   "counters": cnt, "kernel_duration_s_under_profiling": d,
-                   "expected_mfma_busy_cycles": "2*Nq_padded*N*D / 4096 flop per "
-                       "v_mfma_f32_32x32x2_f32 * 64 cycles = 10112*1e6*128*2/4096*64 = 4.045e10",
-                   "mfma_utilisation_lower_bound_at_2.4GHz": busy / (1024 * 2.4e9 * d),
-                   "note": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; the effective "
-                           "clock under load is below 2.4 GHz (DVFS), so the true busy fraction "
-                           "is higher"},
-                  open(f"{out_dir}/{tag}_pmc_mfma_bf_query.json", "w"), indent=1)
-print(open(f"{out_dir}/{tag}_kernel_stats.csv").read()[:1500])
+# ---- L2 (TCC) hit rate and requests that left the L2 ------------------------------------------
+l2 = per_kernel(("l2a", "l2b"), is_trav)
+for k, c in l2.items():
+    if c.get("TCC_REQ_sum"):
+        c["l2_hit_rate"] = c.get("TCC_HIT_sum", 0.0) / (c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 1.0))
+if l2:
+    json.dump({"workload": workload,
+               "command": f"rocprofv3 --pmc TCC_* --kernel-trace --output-format csv -- {CMD} "
+                          "--steps 3 --warmup 1 (two passes)",
+               "units": "per launch; TCC = the 16 L2 channels per XCD; TCC_EA0_RDREQ are read "
+                        "requests the L2 sent on to the fabric (Infinity Cache / HBM; the two are "
+                        "not distinguishable from the GPU side), _DRAM the ones addressed to DRAM",
+               "kernels": l2}, open(f"{out_dir}/{tag}_pmc_l2.json", "w"), indent=1)
+
+# ---- MFMA counters of the brute-force kernel ---------------------------------------------------
+c = collections.defaultdict(list)
+dur = []
+for r in counters("mfma"):
+    if "bf_mfma_kernel" in r["Kernel_Name"]:
+        c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+if c:
+    cnt = {k: sum(v) / len(v) for k, v in c.items()}
+    d = sum(dur) / len(dur)
+    busy = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+    json.dump({"command": "rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
+                          f"SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -- {CMD} "
+                          "--steps 3 --warmup 1",
+               "kernel": "bf_mfma_kernel<float, L2, T=1, NU=16> (10 000 x 1 000 000 x 128 f32, k=10)",
+               "counters": cnt, "kernel_duration_s_under_profiling": d,
+               "expected_mfma_busy_cycles": "2*Nq_padded*N*D / 4096 flop per "
+                   "v_mfma_f32_32x32x2_f32 * 64 cycles = 10112*1e6*128*2/4096*64 = 4.045e10",
+               "mfma_utilisation_lower_bound_at_2.4GHz": busy / (1024 * 2.4e9 * d),
+               "note": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs; the effective "
+                       "clock under load is below 2.4 GHz (DVFS), so the true busy fraction "
+                       "is higher"},
+              open(f"{out_dir}/{tag}_pmc_mfma_bf_query.json", "w"), indent=1)
+
+# other bf shapes (scripts/pmc_bf.sh summaries), if collected in this round
+for shape in ("d960", "d256", "u8"):
+    p = f"gpurun_out/pmc_bf_{shape}/summary.json"
+    if os.path.exists(p):
+        doc = json.load(open(p))
+        for k, v in doc.items():
+            d = v.get("kernel_duration_s_under_profiling")
+            if d and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                v["mfma_busy_fraction_at_2.4GHz"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4e9 * d)
+        json.dump({"command": f"scripts/pmc_bf.sh {shape} ... (rocprofv3 --pmc, three passes over "
+                              "scripts/bf_time*.py: 10 000 queries x 1 000 000 rows, k=10)",
+                   "kernels": doc}, open(f"{out_dir}/{tag}_pmc_bf_{shape}.json", "w"), indent=1)
+
+print(open(f"{out_dir}/{tag}_kernel_stats.csv").read()[:1800])
 for k, v in pmc.items():
-    if "query_kernel" in k and "bf_" not in k and "FETCH_SIZE" in v:
+    if is_query(k) and "FETCH_SIZE" in v:
         f = v["FETCH_SIZE"]["avg_kb"]
         wv = v.get("WRITE_SIZE", {"avg_kb": 0})["avg_kb"]
         print(k, "HBM bytes/launch (corrected):", 2 * f * 1024 + wv * 1024)
+for k, v in l2.items():
+    print(k[:80], {a: round(b, 3) for a, b in v.items()})
