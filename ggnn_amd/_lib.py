@@ -110,6 +110,8 @@ SIGNATURES = {
     "ggnn_op_uniform": (_int, [_vp, _u32, _u64, _u64, _vp]),
     "ggnn_op_sym": (_int, [_vp, _int, _int, _u32, _u32, _vp, _vp, _u32, _vp, _f32, _vp, _vp, _u32,
                            _u32, _vp]),
+    "ggnn_op_sym_prescreened": (_int, [_vp, _vp, _vp, _int, _u32, _u32, _vp, _vp, _u32, _vp, _f32, _vp,
+                                       _vp, _u32, _u32, _vp]),
     "ggnn_op_sym_buffer_merge": (_int, [_u32, _u32, _vp, _vp, _vp, _vp]),
     "ggnn_nn1_stats_scratch_floats": (_sz, []),
     "ggnn_op_nn1_stats": (_int, [_vp, _u32, _vp, _vp, _vp]),

@@ -189,6 +189,10 @@ struct SymLaunch {
   int32_t* sym_buffer;
   uint32_t* sym_atomic;
   uint32_t first_n, count;
+  // optional pre-screen copy of the base (launch_prescreen_encode, same measure); ignored unless float32
+  const uint8_t* ps_codes{nullptr};
+  const float* ps_params{nullptr};
+  uint32_t ps_Dc{0};
 };
 void launch_sym(const SymLaunch& a, hipStream_t stream);
 

@@ -597,6 +597,19 @@ struct ggnn_handle {
                     sym_atomic.as<uint32_t>(),
                     0,
                     cfg.Ns[layer]};
+        // The short sym searches only gain from the pre-screen on wide rows (measured, 1M points:
+        // D = 960 cosine 805 -> 454 ms per build, D = 128 74.6 -> 78.2 ms): used from 1 KB rows on.
+        // GGNN_SYM_PRESCREEN=0|1 forces it off / on (tuning hook).
+        static const int sym_ps_env = [] {
+          const char* e = std::getenv("GGNN_SYM_PRESCREEN");
+          return e ? (e[0] == '0' ? 0 : 1) : -1;
+        }();
+        const bool sym_ps = sym_ps_env >= 0 ? sym_ps_env == 1 : pad_D >= 256;
+        if (use_ps && sym_ps) {
+          s.ps_codes = sh.ps_codes.as<uint8_t>();
+          s.ps_params = sh.ps_params.as<float>();
+          s.ps_Dc = prescreen_code_dim(pad_D);
+        }
         launch_sym(s, stream);
         launch_sym_buffer_merge(K, cfg.Ns[layer], sym_buffer.as<int32_t>(),
                                 sym_atomic.as<uint32_t>(), layer_graph(layer), stream);
@@ -1580,6 +1593,24 @@ ggnn_status ggnn_op_sym(const void* base, ggnn_dtype dtype, ggnn_measure measure
   return guarded(nullptr, [&] {
     SymLaunch s{base,      dtype,     measure,    D,          KBuild,  graph_layer, translation_layer,
                 N_layer,   nn1_stats, tau_build,  sym_buffer, sym_atomic, first_n,  count};
+    launch_sym(s, static_cast<hipStream_t>(stream));
+  });
+}
+
+ggnn_status ggnn_op_sym_prescreened(const float* base, const uint8_t* codes, const float* params,
+                                    ggnn_measure measure, uint32_t D, uint32_t KBuild,
+                                    const int32_t* graph_layer, const int32_t* translation_layer,
+                                    uint32_t N_layer, const float* nn1_stats, float tau_build,
+                                    int32_t* sym_buffer, uint32_t* sym_atomic, uint32_t first_n,
+                                    uint32_t count, void* stream)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(codes && params, GGNN_INVALID_ARGUMENT, "pre-screen buffers are null");
+    SymLaunch s{base,    GGNN_F32,  measure,   D,          KBuild,     graph_layer, translation_layer,
+                N_layer, nn1_stats, tau_build, sym_buffer, sym_atomic, first_n,     count};
+    s.ps_codes = codes;
+    s.ps_params = params;
+    s.ps_Dc = prescreen_code_dim(D);
     launch_sym(s, static_cast<hipStream_t>(stream));
   });
 }

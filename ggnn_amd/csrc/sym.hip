@@ -16,6 +16,10 @@ struct SymArgs {
   uint32_t* sym_atomic;  // [N_layer]
   uint32_t D, KBuild, N_layer, sorted, first_n, count;
   float tau;
+  // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
+  const uint8_t* ps_codes;
+  const float* ps_params;
+  uint32_t ps_Dc;
 };
 
 constexpr uint32_t kSymCache = 128;          // sym_query_layer.cuh:43
@@ -116,14 +120,18 @@ struct SymEngine : DistEngine<BaseT, LPR, NCH> {
 
 // fetch of the sym cache, simple_knn_sym_cache.cuh:405-436
 template <int MODE, int R, class SE>
+GGNN_DEV void sym_distances(SortedList<R>& sl, const SE& se, const WaveLds& lds, const int nsurv,
+                            const int32_t* translation, float criteria_half);
+
+// ps: exact pre-screen on the distance to the query point (traversal.hpp): a candidate whose lower
+// bound already reaches criteria_sym() = s_dists[0] + xi at the start of the fetch fails the
+// first half of the acceptance test (simple_knn_sym_cache.cuh:431) whatever its distance to the
+// half point is -- the criteria only tightens during a fetch -- so its float row is not read.
+template <int MODE, int R, class SE, class PS>
 GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int cand,
-                        const int32_t* translation, float criteria_half)
+                        const int32_t* translation, float criteria_half, const PS& ps)
 {
-  constexpr int STEPS = StepsOf<SE::LPR, SE::NCH>::value;
-  constexpr int ROWS = SE::ROWS;
-  using Chunk = typename SE::Chunk;
   const int lane = threadIdx.x;
-  const int grp = lane / SE::LPR;
   cand = __shfl(cand, lane & 31);
   cand = sl.filter(cand, lds.known);
   const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
@@ -134,6 +142,28 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
   if (lane < 32 && cand != kEmptyKey)
     lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
   __syncthreads();
+  int nsurv_eval = nsurv;
+  if constexpr (PS::enabled) {
+    const float s_thr = ps.threshold(sl.dist_at(0) + sl.xi);
+    if (s_thr < inf_f()) {
+      nsurv_eval = prescreen_pass(ps, lds, nsurv, s_thr, translation);
+      if (nsurv_eval == 0)
+        return;
+      __syncthreads();
+    }
+  }
+  sym_distances<MODE, R>(sl, se, lds, nsurv_eval, translation, criteria_half);
+}
+
+template <int MODE, int R, class SE>
+GGNN_DEV void sym_distances(SortedList<R>& sl, const SE& se, const WaveLds& lds, const int nsurv,
+                            const int32_t* translation, float criteria_half)
+{
+  constexpr int STEPS = StepsOf<SE::LPR, SE::NCH>::value;
+  constexpr int ROWS = SE::ROWS;
+  using Chunk = typename SE::Chunk;
+  const int lane = threadIdx.x;
+  const int grp = lane / SE::LPR;
   for (int s0 = 0; s0 < nsurv; s0 += ROWS * STEPS) {
     Chunk v[STEPS][SE::NCH];
     int rr[STEPS];
@@ -184,7 +214,7 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
   }
 }
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE>
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC>
 // one-chunk layouts fit 7 waves per SIMD without spilling (79 -> 71 registers for uint8 rows)
 __global__ void __launch_bounds__(kWave)
     __attribute__((amdgpu_waves_per_eu((R == 1 && NCH == 1) ? 7 : 1))) sym_kernel(const SymArgs a)
@@ -209,6 +239,12 @@ __global__ void __launch_bounds__(kWave)
   const int m = a.translation ? a.translation[un] : n;
   SymEngine<BaseT, LPR, NCH> se;
   se.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D);
+  // the point is coded like a query (as in the merge kernel)
+  PSC ps;
+  if constexpr (PSC::enabled)
+    ps.load(a.ps_codes, a.ps_params, a.ps_Dc,
+            reinterpret_cast<const float*>(base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D),
+            a.D);
 
   SortedList<R> sl;
   sl.init(KF, a.sorted, kSymCache, xi, lds.known);
@@ -254,7 +290,7 @@ __global__ void __launch_bounds__(kWave)
             found = true;
             break;
           }
-          sym_fetch<MODE>(sl, se, lds, other_id, a.translation, criteria_half);
+          sym_fetch<MODE>(sl, se, lds, other_id, a.translation, criteria_half, ps);
         }
       }
 
@@ -279,18 +315,37 @@ __global__ void __launch_bounds__(kWave)
   }
 }
 
-template <typename BaseT, int LPR, int NCH, int MODE>
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_sym_r(const SymArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kSymCache);
   if (args.sorted <= 64)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE>), grid_for(args.count), dim3(kWave), lds,
-                       stream, args);
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.count), dim3(kWave),
+                       lds, stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE>), grid_for(args.count), dim3(kWave), lds,
-                       stream, args);
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.count), dim3(kWave),
+                       lds, stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the sym cache");
+}
+
+template <typename BaseT, int LPR, int NCH>
+static void launch_sym_cfg(const SymArgs& args, bool use_ps, ggnn_measure measure,
+                           hipStream_t stream)
+{
+  if constexpr (std::is_same<BaseT, float>::value) {
+    if (use_ps) {
+      if (measure == GGNN_EUCLIDEAN)
+        launch_sym_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH, kL2>::type>(args, stream);
+      else
+        launch_sym_r<BaseT, LPR, NCH, kCos, typename PsFor<LPR, NCH, kCos>::type>(args, stream);
+      return;
+    }
+  }
+  if (measure == GGNN_EUCLIDEAN)
+    launch_sym_r<BaseT, LPR, NCH, kL2, NoPrescreen>(args, stream);
+  else
+    launch_sym_r<BaseT, LPR, NCH, kCos, NoPrescreen>(args, stream);
 }
 
 void launch_sym(const SymLaunch& a, hipStream_t stream)
@@ -314,13 +369,15 @@ void launch_sym(const SymLaunch& a, hipStream_t stream)
   if (!args.count)
     return;
 
-#define GGNN_LAUNCH_SYM(T, LPR, NCH)                     \
-  do {                                                   \
-    if (a.measure == GGNN_EUCLIDEAN)                     \
-      launch_sym_r<T, LPR, NCH, kL2>(args, stream);      \
-    else                                                 \
-      launch_sym_r<T, LPR, NCH, kCos>(args, stream);     \
-  } while (0)
+  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
+  if (use_ps) {
+    GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(a.D), GGNN_INVALID_ARGUMENT,
+                 "pre-screen code rows must be D rounded up to 16");
+    args.ps_codes = a.ps_codes;
+    args.ps_params = a.ps_params;
+    args.ps_Dc = a.ps_Dc;
+  }
+#define GGNN_LAUNCH_SYM(T, LPR, NCH) launch_sym_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_SYM);
 #undef GGNN_LAUNCH_SYM
   GGNN_HIP_CHECK(hipGetLastError());

@@ -205,10 +205,19 @@ def uniform(n, seed=1234, stream_id=0, device="cuda"):
 
 
 def sym(base, KBuild, graph_layer, translation_layer, nn1_stats, tau_build, sym_buffer,
-        sym_atomic, measure=EUCLIDEAN, first_n=0, count=None):
+        sym_atomic, measure=EUCLIDEAN, first_n=0, count=None, prescreen=None):
+    """prescreen: optional (codes, params) of prescreen_encode(base, measure) (float32)"""
     N_layer = graph_layer.shape[0]
     if count is None:
         count = N_layer
+    if prescreen is not None:
+        codes, params = prescreen
+        check(lib().ggnn_op_sym_prescreened(_ptr(base), _ptr(codes), _ptr(params), measure,
+                                            base.shape[1], KBuild, _ptr(graph_layer),
+                                            _ptr(translation_layer), N_layer, _ptr(nn1_stats),
+                                            tau_build, _ptr(sym_buffer), _ptr(sym_atomic), first_n,
+                                            count, _stream()))
+        return
     check(lib().ggnn_op_sym(_ptr(base), _dtype_code(base), measure, base.shape[1], KBuild,
                             _ptr(graph_layer), _ptr(translation_layer), N_layer, _ptr(nn1_stats),
                             tau_build, _ptr(sym_buffer), _ptr(sym_atomic), first_n, count,

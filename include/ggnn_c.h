@@ -267,6 +267,15 @@ ggnn_status ggnn_op_sym(const void* base, ggnn_dtype dtype, ggnn_measure measure
                         const int32_t* translation_layer, uint32_t N_layer,
                         const float* nn1_stats, float tau_build, int32_t* sym_buffer,
                         uint32_t* sym_atomic, uint32_t first_n, uint32_t count, void* stream);
+/* ggnn_op_sym for float32 with the pre-screen copy of the base made for `measure`
+ * (ggnn_op_prescreen_encode, params[4] must be 1); same outputs. */
+ggnn_status ggnn_op_sym_prescreened(const float* base, const uint8_t* codes, const float* params,
+                                    ggnn_measure measure, uint32_t D, uint32_t KBuild,
+                                    const int32_t* graph_layer, const int32_t* translation_layer,
+                                    uint32_t N_layer, const float* nn1_stats, float tau_build,
+                                    int32_t* sym_buffer, uint32_t* sym_atomic, uint32_t first_n,
+                                    uint32_t count, void* stream);
+
 /* sym_buffer_merge  sym_buffer_merge_layer.cu:36-99 (sym_buffer is used as scratch) */
 ggnn_status ggnn_op_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buffer,
                                      const uint32_t* sym_atomic, int32_t* graph_layer,

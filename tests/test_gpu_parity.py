@@ -843,6 +843,35 @@ def test_query_and_merge_prescreened_cosine_equal_plain(ops, orc, maker, D):
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("maker,kw,D,measure", [(make_int_data, {}, 128, 0), (_clustered, {}, 128, 0),
+                                                 (_clustered, dict(offset=1000.0), 128, 0),
+                                                 (_clustered, {}, 200, 0), (_clustered, {}, 128, 1),
+                                                 (_clustered, {}, 960, 1)])
+def test_sym_prescreened_equals_plain_sym(ops, orc, maker, kw, D, measure):
+    """the sym kernel with the exact pre-screen on the query-point distance: launched one point at
+    a time (sym is racy by design) it must leave sym_buffer / sym_atomic exactly as the plain
+    kernel does, on a layer-0 graph and on an upper layer (translation)"""
+    N, K = 2500, 24
+    KF = K // 2
+    base = maker(N, D, 131, **kw)
+    cfg, graph, tr, sel, stats = orc.build(base, K, 0.5, 0, measure=measure, rng=orc.make_rng(N, 12))
+    b, ss = dev(base), dev(stats)
+    ps = ops.prescreen_encode(b, measure)
+    assert ps[1].cpu().numpy()[4] == 1.0
+    for layer, Nl in ((0, 160), (1, 80)):
+        g_l = dev(graph[cfg.Ns_offsets[layer]:cfg.Ns_offsets[layer] + cfg.Ns[layer]].copy())
+        t_l = None if layer == 0 else dev(tr[cfg.STs_offsets[layer]:cfg.STs_offsets[layer] + cfg.Ns[layer]])
+        out = []
+        for pre in (None, ps):
+            sb = torch.full((cfg.Ns[layer], KF), -1, dtype=torch.int32, device="cuda")
+            sa = torch.zeros(cfg.Ns[layer], dtype=torch.int32, device="cuda")
+            for n in range(Nl):
+                ops.sym(b, K, g_l, t_l, ss, 0.5, sb, sa, measure, first_n=n, count=1, prescreen=pre)
+            out.append((sb, sa))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert int(out[0][1].sum()) > 0     # some inverse links were requested at all
+
+
 @pytest.mark.parametrize("K", [20, 40])
 def test_prescreen_other_graph_degrees(ops, orc, K):
     """KBuild = 40 needs two fetch blocks per pop, KBuild = 20 leaves lanes of a block empty"""
