@@ -55,3 +55,57 @@ def test_two_ranks_real_engine(orc, tmp_path, world, spg):
     rec = np.mean([len(set(a) & set(b)) / K for a, b in zip(z["ids"], z["gt"])])
     assert rec >= 0.97, rec
     assert z["ids"].max() >= shard * spg          # ids of the second rank's slice are offset
+
+
+def _json_line(stdout):
+    import json
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_strong_scaling_line(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU), here
+    with both ranks on GPU 0 over gloo and a small base: the strong-scaling line must carry
+    queries/s on the fixed 8-shard base, the one-GPU point of the same base and the speed-up."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() % 400) + 57
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--single-device",
+           "--n-base", "20000", "--n-query", "600", "--tau-query", "1.0", "--max-iters", "400"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "queries/s" and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert abs(d["value"] - 600 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "8 shards x 20000" in d["config"]["workload"]
+    assert d["recall_at_10"] > 0.95
+    one = d["one_gpu_same_base"]
+    assert one["recall_at_10"] > 0.95 and one["queries_per_s"] > 0
+    assert abs(d["speedup_vs_one_gpu_same_base"] - d["value"] / one["queries_per_s"]) < 1e-9
+
+
+def test_bench_single_gpu_line_small():
+    """the N=1 line on a small base: contract fields, roofline and cpu_baseline objects, the
+    dataset block and the one-GPU point of the strong-scaling series"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+           "--n-base", "20000", "--n-query", "600", "--tau-query", "1.0", "--max-iters", "400"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = _json_line(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["recall_at_10"] > 0.95 and d["recall_at_10_heldout_queries"] > 0.95
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "valu") and 0 < rf["frac"] and "hbm" in rf
+    assert rf["without_prescreen"]["results"].startswith("bit-identical")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert set(d["datasets"]["results"]) >= {"lowrank16", "lowrank24", "lowrank32", "iid"}
+    assert d["strong_scaling_one_gpu"]["queries_per_s"] > 0
+    assert d["build"]["merge_kernel"]["prescreened"]["ms"] > 0
