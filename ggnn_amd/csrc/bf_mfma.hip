@@ -1003,13 +1003,17 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t parts = static_cast<size_t>(slices) * a.Nq * KP;
   uint32_t rescan_slices = 0;
   const size_t rescan_entries = use_i8 ? 0 : bf_rescan_tmp_entries(a, &rescan_slices);
-  const size_t n_norms = (static_cast<size_t>(a.N_base) + a.Nq + 3) / 4 * 4;
-  const size_t n_mean = (static_cast<size_t>(a.D) + 3) / 4 * 4;
+  // every block starts on a 16-byte boundary (float4 / int4 accesses)
+  auto pad4 = [](size_t words) { return (words + 3) / 4 * 4; };
+  const size_t n_norms = pad4(static_cast<size_t>(a.N_base) + a.Nq);
+  const size_t n_mean = pad4(a.D);
   const size_t n_partial = center ? static_cast<size_t>(kBfMeanBlocks) * n_mean : 0;
-  const size_t n_list = (static_cast<size_t>(a.Nq) + 3) / 4 * 4;
+  const size_t n_list = pad4(a.Nq);
+  const size_t n_parts = pad4(parts);
+  const size_t n_rescan = pad4(rescan_entries);
   const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
   const size_t words =
-      n_norms + n_mean + n_partial + 4 + n_list + 2 * parts + 2 * rescan_entries + n_qshift;
+      n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan + n_qshift;
   float* scratch = nullptr;
   GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), words * 4, stream));
   float* bnorm = scratch;
@@ -1019,10 +1023,10 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   uint32_t* flags = reinterpret_cast<uint32_t*>(partial + n_partial);  // [0] bn_max [1] count
   uint32_t* rescan_list = flags + 4;
   int32_t* part_ids = reinterpret_cast<int32_t*>(rescan_list + n_list);
-  float* part_dists = reinterpret_cast<float*>(part_ids + parts);
-  int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + parts);
-  float* rescan_dists = reinterpret_cast<float*>(rescan_ids + rescan_entries);
-  float* q_shifted = rescan_dists + rescan_entries;  // 16-byte aligned: every block above is
+  float* part_dists = reinterpret_cast<float*>(part_ids + n_parts);
+  int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + n_parts);
+  float* rescan_dists = reinterpret_cast<float*>(rescan_ids + n_rescan);
+  float* q_shifted = rescan_dists + n_rescan;
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
 
   if (center) {

@@ -184,3 +184,15 @@ def test_engine_reports_rescanned_queries(orc):
     gt, gd = eng.bf_query(q, 10)
     assert eng.last_bf_query_rescanned() == 0
     check_against_float64(base, q, gt.numpy(), 10, 0)
+
+
+@pytest.mark.parametrize("N,Nq,K,D", [(4500, 257, 1, 128), (4500, 259, 3, 100), (9100, 301, 5, 200)])
+def test_bf_mfma_odd_sizes(ops, orc, N, Nq, K, D):
+    """odd slice / query / list counts: every scratch block of the MFMA path must stay 16-byte
+    aligned (the shifted query copy sits behind the candidate buffers)"""
+    base, q = _clustered(N, D, 551, 1000.0), _clustered(Nq, D, 552, 1000.0)
+    b, qq = dev(base), dev(q)
+    ids, dists, _ = ops.bf_query(b, qq, K, 0, rescanned=True)
+    s_ids, s_dists = scan_answer(ops, b, qq, K, 0)
+    assert torch.equal(ids, s_ids) and torch.equal(dists, s_dists)
+    check_against_float64(base, q, ids.cpu().numpy(), K, 0)
