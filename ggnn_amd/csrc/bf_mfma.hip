@@ -398,12 +398,54 @@ GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t r
   }
 }
 
+// Query operands of the chunked kernel are fetched with BUFFER loads through a descriptor that
+// spans exactly this workgroup's query rows: out-of-range offsets return zero in hardware, so
+// padding queries (rows past Nq) and columns past D need neither a branch nor a select, the value
+// lands directly in the operand registers and nothing waits for it until the next chunk's MFMAs.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <typename BaseT>
+struct QueryWindow {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t row_bytes;   // byte offset of this lane's query row inside the window
+  uint32_t D;
+  GGNN_DEV void open(const BaseT* query, uint32_t Nq, uint32_t D_, uint32_t q0, uint32_t row)
+  {
+    const uint32_t rows = Nq > q0 ? min(static_cast<uint32_t>(kBfQueriesPerBlock), Nq - q0) : 0u;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<BaseT*>(query + static_cast<size_t>(q0) * D_), 0,
+        rows * D_ * static_cast<uint32_t>(sizeof(BaseT)), 0x00020000);
+    row_bytes = row * D_ * static_cast<uint32_t>(sizeof(BaseT));
+    D = D_;
+  }
+  // four operands of piece t (columns col_h + 4t ...) of a chunk
+  GGNN_DEV float4 piece(uint32_t col_h, int t) const
+  {
+    const uint32_t col = col_h + 4 * t;
+    // past the row: an offset outside the window, which reads as zero
+    const uint32_t off = col < D ? row_bytes + col * static_cast<uint32_t>(sizeof(BaseT))
+                                 : 0xffffffffu;
+    if constexpr (std::is_same<BaseT, float>::value) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                         __uint_as_float(v.w));
+    }
+    else {
+      const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+      return make_float4(static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu),
+                         static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24));
+    }
+  }
+};
+
 // 4*NU MFMA steps of one (tile, chunk) pair: acc += aq x B with B read from the LDS tile row bt.
 // PREFETCH: every group of four query operands is reloaded for the next chunk (columns from
-// next_col on) right after its MFMAs have been issued.
+// next_col on) right after its MFMAs have been issued.  The scheduling recipe at the end pins the
+// software pipeline -- B operand of step u+1 from LDS, the four MFMAs of step u, the query piece u
+// of the next chunk -- so that the prefetched values reuse the operand registers they replace
+// (hoisting all sixteen loads needs 64 more registers: 55 spills at two waves per SIMD).
 template <int NU, bool PREFETCH, typename BaseT>
-GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt, const BaseT* qrow,
-                         bool qvalid, uint32_t D, uint32_t Dh, uint32_t next_col)
+GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt,
+                         const QueryWindow<BaseT>& qw, uint32_t next_col)
 {
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -413,12 +455,21 @@ GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt, const Ba
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc, 0, 0, 0);
     if (PREFETCH) {
-      const float4 nq = load_query_piece(qrow, qvalid, D, Dh, next_col, u);
+      const float4 nq = qw.piece(next_col, u);
       aq[4 * u + 0] = nq.x;
       aq[4 * u + 1] = nq.y;
       aq[4 * u + 2] = nq.z;
       aq[4 * u + 3] = nq.w;
     }
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (B operand of step 0)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (u + 1 < NU)
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read of step u+1
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // the four MFMAs of step u
+    if (PREFETCH)
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // query piece u of the next chunk
   }
 }
 
@@ -446,7 +497,10 @@ __global__ void __launch_bounds__(256)
   // the two tile buffers are addressed as lds_f + offset (never through a pointer array: a select
   // between pointers decays to generic addressing, i.e. flat loads that wait on vmcnt(0) and with
   // it on the prefetch of the next tile)
-  const uint32_t tile_floats = kBfTileRows * a.DP;
+  // chunk geometry from the template parameter: the staging index arithmetic (idx / cpr, idx % cpr)
+  // is then shifts and masks instead of run-time integer division
+  constexpr uint32_t Dh = 4 * NU, CW = 2 * Dh, DP = CW + ((CW % 8 == 0) ? 4 : 8);
+  const uint32_t tile_floats = kBfTileRows * DP;
   float* list_d = lds_f + 2 * tile_floats;
   int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
 
@@ -458,7 +512,6 @@ __global__ void __launch_bounds__(256)
   const uint32_t begin = blockIdx.y * a.rows_per_slice;
   const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
   const uint32_t KP = a.KP;
-  const uint32_t CW = 2 * a.Dh;
   const uint32_t nch = (a.D + CW - 1) / CW;
 
   // candidate lists of this wave's 32 queries; padding queries get -inf so that nothing ever
@@ -497,11 +550,14 @@ __global__ void __launch_bounds__(256)
   }
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
-    stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
-    if constexpr (T > 1)
-      stage.store_shifted(lds_f, a.DP, CW, mean_lds, 0);
-    else
-      stage.store(lds_f, a.DP, CW);
+    if constexpr (T > 1) {
+      stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
+      stage.store_shifted(lds_f, DP, CW, mean_lds, 0);
+    }
+    else {
+      stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
+      stage.store(lds_f, DP, CW);
+    }
   }
   __syncthreads();
 
@@ -510,7 +566,7 @@ __global__ void __launch_bounds__(256)
     // of tile t -- its 16 x (add, fma, compare) are independent of the running accumulator, so
     // the matrix pipe does not drain between tiles.  Before the first tile the "previous"
     // accumulator is a dummy whose distances are +inf.
-    load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
+    load_query_chunk(aq, qrow, qvalid, a.D, Dh, h * Dh);
     f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bn_prev = bn_pad;
     bool jvalid_prev = false;
@@ -526,12 +582,12 @@ __global__ void __launch_bounds__(256)
       const bool jvalid = row0 + j < end;
       // norm of this lane's tile row, staged next to the tile (an LDS read: a global load here
       // would make the compiler wait for vmcnt(0), i.e. for the prefetch of the next tile)
-      const float bn = lds_f[(tt & 1) * tile_floats + j * a.DP + CW];
+      const float bn = lds_f[(tt & 1) * tile_floats + j * DP + CW];
       const bool has_next = tt + 1 < ntiles;
       if (has_next)
         stage.load(base, a.D, row0 + kBfTileRows, end, 0, CW, a.bnorm, bn_pad);
       f32x16 acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const float* bt = lds_f + (tt & 1) * tile_floats + j * a.DP + h * a.Dh;
+      const float* bt = lds_f + (tt & 1) * tile_floats + j * DP + h * Dh;
       float dd[16];
       unsigned long long any = 0;
 #pragma unroll
@@ -549,7 +605,7 @@ __global__ void __launch_bounds__(256)
       if (any)
         bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
       if (has_next)
-        stage.store(lds_f + ((tt + 1) & 1) * tile_floats, a.DP, CW);
+        stage.store(lds_f + ((tt + 1) & 1) * tile_floats, DP, CW);
       __syncthreads();
       acc_prev = acc;
       bn_prev = bn;
@@ -569,6 +625,9 @@ __global__ void __launch_bounds__(256)
     }
   }
   else {
+  // this workgroup's 128 query rows as a buffer window (rows past Nq are out of range: zero)
+  QueryWindow<BaseT> qw;
+  qw.open(query, a.Nq, a.D, blockIdx.x * kBfQueriesPerBlock, wave * 32 + j);
   uint32_t p = 0;  // (tile, chunk) pairs processed: buffer p&1 holds the current pair
   for (uint32_t g0 = 0; g0 < ntiles; g0 += T) {
     f32x16 acc[T];
@@ -579,9 +638,17 @@ __global__ void __launch_bounds__(256)
     for (uint32_t c = 0; c < nch; ++c) {
       // the query chunk of (g0, c) was loaded during the last tile of the previous (group, chunk)
       // -- see below -- except for the very first one
-      if (g0 == 0 && c == 0)
-        load_query_chunk(aq, qrow, qvalid, a.D, a.Dh, h * a.Dh);
-      const uint32_t next_col = ((c + 1 < nch) ? (c + 1) * CW : 0u) + h * a.Dh;
+      if (g0 == 0 && c == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float4 v = qw.piece(h * Dh, t);
+          aq[4 * t + 0] = v.x;
+          aq[4 * t + 1] = v.y;
+          aq[4 * t + 2] = v.z;
+          aq[4 * t + 3] = v.w;
+        }
+      }
+      const uint32_t next_col = ((c + 1 < nch) ? (c + 1) * CW : 0u) + h * Dh;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t tt = g0 + t;
@@ -611,15 +678,15 @@ __global__ void __launch_bounds__(256)
         // the last tile of a chunk every group of four query operands is reloaded for the NEXT
         // chunk as soon as its MFMAs have been issued: the loads travel while the rest of the
         // chain runs, instead of stalling the first MFMA of the next chunk.
-        const float* bt = lds_f + (p & 1) * tile_floats + j * a.DP + h * a.Dh;
+        const float* bt = lds_f + (p & 1) * tile_floats + j * DP + h * Dh;
         // two copies of the chain, the branch outside: each is ONE basic block, so the LDS reads
         // of the B operand are scheduled ahead of the MFMAs that consume them
         if (last_of_chunk)
-          mfma_chain<NU, true>(acc[t], aq, bt, qrow, qvalid, a.D, a.Dh, next_col);
+          mfma_chain<NU, true>(acc[t], aq, bt, qw, next_col);
         else
-          mfma_chain<NU, false>(acc[t], aq, bt, qrow, qvalid, a.D, a.Dh, next_col);
+          mfma_chain<NU, false>(acc[t], aq, bt, qw, next_col);
         if (has_next)
-          stage.store_shifted(lds_f + ((p + 1) & 1) * tile_floats, a.DP, CW, mean_lds,
+          stage.store_shifted(lds_f + ((p + 1) & 1) * tile_floats, DP, CW, mean_lds,
                               n_chunk * CW);
         __syncthreads();
         ++p;
