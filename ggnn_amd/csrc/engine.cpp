@@ -203,6 +203,13 @@ struct DeviceCtx {
   std::vector<Shard> shards;
   float build_ms{0.f}, query_ms{0.f};
   uint64_t n_dist{0}, n_pop{0}, n_float_rows{0}, n_code_rows{0};
+  // several resident shards: their query kernels run on a few extra streams so that the thin tail
+  // of one launch overlaps with the head of the next (the reference also uses per-shard streams,
+  // gpu_instance.cu:626-743)
+  static constexpr int kShardStreams = 4;
+  hipStream_t shard_stream[kShardStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t shard_done[kShardStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_ready{nullptr};
   DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
   // result staging of query(): grown on demand, kept between calls
   DeviceBuffer r_ids, r_dists;  // this GPU's sorted rows [Nq, K * shards_per_gpu]
@@ -224,8 +231,15 @@ struct DeviceCtx {
     stream = o.stream;
     ev_a = o.ev_a;
     ev_b = o.ev_b;
+    ev_ready = o.ev_ready;
+    for (int i = 0; i < kShardStreams; ++i) {
+      shard_stream[i] = o.shard_stream[i];
+      shard_done[i] = o.shard_done[i];
+      o.shard_stream[i] = nullptr;
+      o.shard_done[i] = nullptr;
+    }
     o.stream = nullptr;
-    o.ev_a = o.ev_b = nullptr;
+    o.ev_a = o.ev_b = o.ev_ready = nullptr;
     base_copy = std::move(o.base_copy);
     bf_rescanned = std::move(o.bf_rescanned);
     r_ids = std::move(o.r_ids);
@@ -245,6 +259,13 @@ struct DeviceCtx {
       (void)hipSetDevice(device);
       (void)hipEventDestroy(ev_a);
       (void)hipEventDestroy(ev_b);
+      if (ev_ready)
+        (void)hipEventDestroy(ev_ready);
+      for (int i = 0; i < kShardStreams; ++i)
+        if (shard_stream[i]) {
+          (void)hipEventDestroy(shard_done[i]);
+          (void)hipStreamDestroy(shard_stream[i]);
+        }
       (void)hipStreamDestroy(stream);
     }
   }
@@ -255,6 +276,17 @@ struct DeviceCtx {
       GGNN_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       GGNN_HIP_CHECK(hipEventCreate(&ev_a));
       GGNN_HIP_CHECK(hipEventCreate(&ev_b));
+    }
+  }
+  // (after activate(); created with the first multi-shard query)
+  void ensure_shard_streams()
+  {
+    if (shard_stream[0])
+      return;
+    GGNN_HIP_CHECK(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < kShardStreams; ++i) {
+      GGNN_HIP_CHECK(hipStreamCreateWithFlags(&shard_stream[i], hipStreamNonBlocking));
+      GGNN_HIP_CHECK(hipEventCreateWithFlags(&shard_done[i], hipEventDisableTiming));
     }
   }
 };
@@ -779,6 +811,23 @@ struct ggnn_handle {
     ctx.query_ms = 0.f;
     ctx.n_dist = ctx.n_pop = ctx.n_float_rows = ctx.n_code_rows = 0;
     std::vector<uint32_t> h_cnt;
+    // Several resident shards: one launch per shard, spread over a few streams and NOT separated
+    // by host synchronisation, so the under-occupied tail of a 10k-wave launch is filled by the
+    // next shard's waves (GGNN_SHARD_OVERLAP=0: one launch at a time, as for the work counters).
+    static const bool overlap_env = [] {
+      const char* e = std::getenv("GGNN_SHARD_OVERLAP");
+      return !(e && e[0] == '0');
+    }();
+    const bool overlap = spg > 1 && !collect_counters && overlap_env;
+    if (overlap) {
+      for (uint32_t si = 0; si < spg; ++si)
+        (void)ensure_prescreen(ctx, si, measure);  // may code a shard (synchronises): do it first
+      ctx.ensure_shard_streams();
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_ready, stream));  // query staged, earlier work done
+      for (int i = 0; i < DeviceCtx::kShardStreams; ++i)
+        GGNN_HIP_CHECK(hipStreamWaitEvent(ctx.shard_stream[i], ctx.ev_ready, 0));
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_a, stream));
+    }
     for (uint32_t si = 0; si < spg; ++si) {
       const bool use_ps = ensure_prescreen(ctx, si, measure);
       const Shard& sh = ctx.shards[si];
@@ -809,6 +858,10 @@ struct ggnn_handle {
         ql.ps_Dc = prescreen_code_dim(pad_D);
       }
       ql.n_rows = c_rows.as<uint32_t>();
+      if (overlap) {
+        launch_query(ql, ctx.shard_stream[si % DeviceCtx::kShardStreams]);
+        continue;
+      }
       EventTimer timer(stream, ctx.ev_a, ctx.ev_b);
       launch_query(ql, stream);
       const float ms = timer.stop();
@@ -831,9 +884,22 @@ struct ggnn_handle {
         }
       }
     }
+    if (overlap) {
+      // join: the main stream continues (timing event, row sort) after every shard stream
+      for (int i = 0; i < DeviceCtx::kShardStreams; ++i) {
+        GGNN_HIP_CHECK(hipEventRecord(ctx.shard_done[i], ctx.shard_stream[i]));
+        GGNN_HIP_CHECK(hipStreamWaitEvent(stream, ctx.shard_done[i], 0));
+      }
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_b, stream));
+    }
     if (spg > 1)
       launch_sort_shard_results(nq, k_query * spg, d_ids, d_dists, stream);
     GGNN_HIP_CHECK(hipStreamSynchronize(stream));
+    if (overlap) {
+      GGNN_HIP_CHECK(hipEventElapsedTime(&ctx.query_ms, ctx.ev_a, ctx.ev_b));
+      GGNN_LOG(0, "[GPU: %d] query parts %u..%u overlapped => ms: %.3f [%u points query]",
+               ctx.device, ctx.first_shard, ctx.first_shard + spg - 1, ctx.query_ms, nq);
+    }
   }
 
   // GGNNImpl::queryImpl, ggnn.cu:278-330

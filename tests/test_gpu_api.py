@@ -244,6 +244,28 @@ def test_rccl_exchange_single_rank_world(orc, monkeypatch):
     assert torch.equal(ids[:1], ids3) and torch.equal(d[:1], d3)
 
 
+def test_overlapped_shard_launches_equal_sequential():
+    """several resident shards: the per-shard kernels run concurrently on a few streams; with the
+    work counters switched on they run one at a time -- same sorted rows either way"""
+    import ggnn_amd as ggnn
+    base, q = make_int_data(12000, 64, 195), make_int_data(500, 64, 196)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_shard_size(2000)                 # 6 shards on 4 streams
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 1)
+    ids, d = eng.query(q, 10, 0.7, 200)
+    assert tuple(ids.shape) == (500, 60)
+    eng.set_collect_counters(True)
+    ids2, d2 = eng.query(q, 10, 0.7, 200)
+    assert eng.last_query_counters()["n_pop"] > 0
+    eng.set_collect_counters(False)
+    ids3, d3 = eng.query(q, 10, 0.7, 200)
+    assert torch.equal(ids, ids2) and torch.equal(d, d2)
+    assert torch.equal(ids, ids3) and torch.equal(d, d3)
+    assert (d[:, 1:] >= d[:, :-1]).all()     # rows sorted across shards
+
+
 def test_failed_load_rolls_back(tmp_path):
     """a load() that fails half way must not leave a handle that claims a graph."""
     import ggnn_amd as ggnn
