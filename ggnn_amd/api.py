@@ -275,6 +275,26 @@ class GGNN:
                                      dists.data_ptr(), _lib.GPU if on_gpu else _lib.CPU))
         return ids, dists
 
+    def query_async(self, query, k_query, tau_query, max_iterations=400,
+                    measure=DistanceMeasure.Euclidean, slot=0):
+        """Extension for serving: enqueue a batch and return GPU tensors that are valid after
+        `synchronize()`.  Batches with different `slot`s overlap on the device (one GPU, query on
+        that GPU); the result has the results-on-GPU shape [Nq, k_query * shards]."""
+        t = _as_tensor(query, what="query")
+        if not t.is_cuda:
+            raise RuntimeError("query_async needs the query on the GPU")
+        loc, dev = _loc(t)
+        ids, dists = self._out(t.shape[0], int(k_query) * self._shards, True, t.device)
+        self._check(lib().ggnn_query_async(self._h, t.data_ptr(), t.shape[0], t.shape[1],
+                                           _dtype_code(t), dev, int(k_query), float(tau_query),
+                                           int(max_iterations), int(measure), ids.data_ptr(),
+                                           dists.data_ptr(), int(slot)))
+        return ids, dists
+
+    def synchronize(self):
+        """wait for every batch enqueued with query_async"""
+        self._check(lib().ggnn_synchronize(self._h))
+
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
         """Run a brute-force query and indices and distances."""
         t = _as_tensor(query, what="query")

@@ -1044,6 +1044,61 @@ struct ggnn_handle {
     last_exchange = "copy";
   }
 
+  // Extension for serving: enqueue one query batch and return.  Consecutive batches given
+  // different slots run on different streams, so the under-occupied tail of one batch's launch
+  // overlaps with the head of the next (a lone 10k-query launch is latency-bound).
+  // Restrictions: one GPU; query and result arrays already on that GPU (nothing is staged);
+  // results are the sorted [Nq, K * shards] rows of results-on-GPU mode (ggnn.cuh:108-113) and are
+  // valid after synchronize().
+  void query_async(const void* d_query, uint64_t Nq, uint32_t D, ggnn_dtype dtype, int q_gpu,
+                   uint32_t k_query, float tau_query, uint32_t max_iterations,
+                   ggnn_measure measure, int32_t* d_ids, float* d_dists, uint32_t slot)
+  {
+    GGNN_REQUIRE(has_graph(), GGNN_INVALID_STATE, "There is no graph to query.");
+    GGNN_REQUIRE(devs.size() == 1, GGNN_INVALID_STATE,
+                 "Asynchronous queries are only possible when using a single GPU.");
+    check_query(Nq, D, dtype, d_query);
+    DeviceCtx& ctx = devs[0];
+    GGNN_REQUIRE(q_gpu == ctx.device, GGNN_INVALID_ARGUMENT,
+                 "asynchronous queries need the query on the engine's GPU");
+    GGNN_REQUIRE(pad_D == base_D && (reinterpret_cast<uintptr_t>(d_query) & 15u) == 0,
+                 GGNN_UNSUPPORTED,
+                 "asynchronous queries need 16-byte aligned rows (no padding is staged)");
+    if (!Nq)
+      return;
+    ctx.activate();
+    for (uint32_t si = 0; si < shards_per_gpu; ++si)
+      (void)ensure_prescreen(ctx, si, measure);
+    ctx.ensure_shard_streams();
+    hipStream_t stream = ctx.shard_stream[slot % DeviceCtx::kShardStreams];
+    const uint32_t nq = static_cast<uint32_t>(Nq);
+    for (uint32_t si = 0; si < shards_per_gpu; ++si) {
+      const Shard& sh = ctx.shards[si];
+      QueryLaunch ql{shard_base(ctx, si), d_query, base_dtype, cfg.N, pad_D, nq, sh.graph,
+                     cfg.KBuild, sh.translation + cfg.STs_offsets[kLayers - 1], cfg.S,
+                     sh.nn1_stats, k_query, tau_query, max_iterations, measure, shards_per_gpu, si,
+                     d_ids, d_dists, nullptr, nullptr};
+      if (sh.ps_state > 0 && sh.ps_measure == measure) {
+        ql.ps_codes = sh.ps_codes.as<uint8_t>();
+        ql.ps_params = sh.ps_params.as<float>();
+        ql.ps_Dc = prescreen_code_dim(pad_D);
+      }
+      launch_query(ql, stream);
+    }
+    if (shards_per_gpu > 1)
+      launch_sort_shard_results(nq, k_query * shards_per_gpu, d_ids, d_dists, stream);
+  }
+  void synchronize()
+  {
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      for (int i = 0; i < DeviceCtx::kShardStreams; ++i)
+        if (ctx.shard_stream[i])
+          GGNN_HIP_CHECK(hipStreamSynchronize(ctx.shard_stream[i]));
+    }
+  }
+
   // GGNNImpl::bfQueryImpl, ggnn.cu:332-390
   void bf_query(const void* q, uint64_t Nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
                 int q_gpu, uint32_t k_gt, ggnn_measure measure, int32_t* ids_out,
@@ -1400,6 +1455,24 @@ ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, gg
     h->query(query, Nq, D, dtype, location, gpu_id, k_query, tau_query, max_iterations, measure,
              ids_out, dists_out, out_location);
   });
+}
+
+ggnn_status ggnn_query_async(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
+                             ggnn_dtype dtype, int gpu_id, uint32_t k_query, float tau_query,
+                             uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
+                             float* dists_out, uint32_t slot)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    h->query_async(query, Nq, D, dtype, gpu_id, k_query, tau_query, max_iterations, measure,
+                   ids_out, dists_out, slot);
+  });
+}
+
+ggnn_status ggnn_synchronize(ggnn_t* h)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] { h->synchronize(); });
 }
 
 ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,

@@ -95,6 +95,18 @@ ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, gg
                        uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
                        float* dists_out, ggnn_location out_location);
 
+/* Extension for serving (no counterpart in the reference, whose query() blocks,
+ * gpu_instance.cu:687-712): enqueue one batch and return.  Batches given different `slot`s run on
+ * different streams, so the thin tail of one batch's launch overlaps with the next batch.
+ * One GPU only; `query`, `ids_out`, `dists_out` are device memory on that GPU, rows 16-byte
+ * aligned; the results are the sorted [Nq, k_query * shards] rows of results-on-GPU mode and are
+ * valid after ggnn_synchronize(). */
+ggnn_status ggnn_query_async(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
+                             ggnn_dtype dtype, int gpu_id, uint32_t k_query, float tau_query,
+                             uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
+                             float* dists_out, uint32_t slot);
+ggnn_status ggnn_synchronize(ggnn_t* h);
+
 /* bfQuery ggnn.cuh:162-172, ggnn.cu:543-564 */
 ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
                           ggnn_dtype dtype, ggnn_location location, int gpu_id, uint32_t k_gt,

@@ -266,6 +266,33 @@ def test_overlapped_shard_launches_equal_sequential():
     assert (d[:, 1:] >= d[:, :-1]).all()     # rows sorted across shards
 
 
+@pytest.mark.parametrize("shard_size", [0, 3000])
+def test_query_async_equals_blocking_query(shard_size):
+    """query_async / synchronize (serving extension): batches enqueued on alternating slots give
+    the rows of the blocking results-on-GPU call, for one and for several resident shards"""
+    import ggnn_amd as ggnn
+    base, q = make_int_data(12000, 64, 197), make_int_data(700, 64, 198)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    if shard_size:
+        eng.set_shard_size(shard_size)
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 1)
+    qd = torch.from_numpy(q).cuda()
+    qd2 = torch.from_numpy(q[::-1].copy()).cuda()
+    ref = eng.query(qd, 10, 0.7, 200)
+    ref2 = eng.query(qd2, 10, 0.7, 200)
+    outs = []
+    for i in range(6):
+        outs.append(eng.query_async(qd if i % 2 == 0 else qd2, 10, 0.7, 200, slot=i))
+    eng.synchronize()
+    for i, (ids, d) in enumerate(outs):
+        want = ref if i % 2 == 0 else ref2
+        assert torch.equal(ids, want[0]) and torch.equal(d, want[1])
+    with pytest.raises(RuntimeError, match="on the GPU"):
+        eng.query_async(q, 10, 0.7, 200)
+
+
 def test_failed_load_rolls_back(tmp_path):
     """a load() that fails half way must not leave a handle that claims a graph."""
     import ggnn_amd as ggnn
