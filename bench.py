@@ -551,6 +551,36 @@ def run_sharded(args, device, ggnn, world, rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     recall = recall_at_k(ids, gt)
+
+    # informational: two batches in flight per rank (local search of batch i+1 enqueued before
+    # batch i is exchanged and merged); not part of `value`
+    pipelined = None
+    if not args.no_pipelined:
+        try:
+            tickets = [sharded.query_async(query, args.k, args.tau_query, args.max_iters, slot=0)]
+            sharded.finish(tickets.pop())
+            barrier()
+            t0 = time.perf_counter()
+            last = None
+            for i in range(args.steps):
+                tickets.append(sharded.query_async(query, args.k, args.tau_query, args.max_iters,
+                                                   slot=i % 2))
+                if len(tickets) == 2:
+                    last = sharded.finish(tickets.pop(0))
+            while tickets:
+                last = sharded.finish(tickets.pop(0))
+            barrier()
+            pip = time.perf_counter() - t0
+            tp = torch.tensor([pip], dtype=torch.float64,
+                              device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            pip = float(tp.item()) / args.steps
+            same = bool(torch.equal(last[0], ids) and torch.equal(last[1], dists))
+            pipelined = {"batches_in_flight": 2, "ms_per_batch": pip * 1e3,
+                         "queries_per_s": args.n_query / pip,
+                         "results_equal_blocking": same}
+        except Exception as e:  # informational only: never lose the main line over it
+            pipelined = {"error": repr(e)}
     del sharded, eng, base
     torch.cuda.empty_cache()
 
@@ -584,6 +614,10 @@ def run_sharded(args, device, ggnn, world, rank):
             "query_kernel_ms_sum_over_local_shards": float(np.mean(kernel_ms)),
             "one_gpu_same_base": one,
             "speedup_vs_one_gpu_same_base": (None if one is None else value / one["queries_per_s"]),
+            "pipelined_batches": pipelined,
+            "pipelined_speedup_vs_one_gpu_same_base": (
+                None if one is None or not pipelined or "queries_per_s" not in pipelined
+                else pipelined["queries_per_s"] / one["queries_per_s"]),
             "roofline": None, "cpu_baseline": None,
             "note": "N=1 of this command is the BASELINE single-shard configuration; the "
                     "multi-GPU series keeps the BASE fixed (8 shards) instead, so compare with "

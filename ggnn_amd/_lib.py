@@ -77,6 +77,7 @@ SIGNATURES = {
     "ggnn_query_async": (_int, [_vp, _vp, _u64, _u32, _int, _int, _u32, _f32, _u32, _int, _vp, _vp,
                                 _u32]),
     "ggnn_synchronize": (_int, [_vp]),
+    "ggnn_synchronize_slot": (_int, [_vp, _u32]),
     "ggnn_bf_query": (_int, [_vp, _vp, _u64, _u32, _int, _int, _int, _u32, _int, _vp, _vp, _int]),
     "ggnn_get_graph": (_int, [_vp, _u32, C.POINTER(GraphView)]),
     "ggnn_last_timing_ms": (_int, [_vp, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)]),

@@ -291,9 +291,12 @@ class GGNN:
                                            dists.data_ptr(), int(slot)))
         return ids, dists
 
-    def synchronize(self):
-        """wait for every batch enqueued with query_async"""
-        self._check(lib().ggnn_synchronize(self._h))
+    def synchronize(self, slot=None):
+        """wait for every batch enqueued with query_async (or only for those of one slot)"""
+        if slot is None:
+            self._check(lib().ggnn_synchronize(self._h))
+        else:
+            self._check(lib().ggnn_synchronize_slot(self._h, int(slot)))
 
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
         """Run a brute-force query and indices and distances."""

@@ -1088,6 +1088,16 @@ struct ggnn_handle {
     if (shards_per_gpu > 1)
       launch_sort_shard_results(nq, k_query * shards_per_gpu, d_ids, d_dists, stream);
   }
+  // wait for the batches enqueued on one slot only (the other slots keep running)
+  void synchronize_slot(uint32_t slot)
+  {
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      hipStream_t st = ctx.shard_stream[slot % DeviceCtx::kShardStreams];
+      if (st)
+        GGNN_HIP_CHECK(hipStreamSynchronize(st));
+    }
+  }
   void synchronize()
   {
     for (DeviceCtx& ctx : devs) {
@@ -1473,6 +1483,12 @@ ggnn_status ggnn_synchronize(ggnn_t* h)
 {
   GGNN_NEED_HANDLE(h);
   return guarded(h, [&] { h->synchronize(); });
+}
+
+ggnn_status ggnn_synchronize_slot(ggnn_t* h, uint32_t slot)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] { h->synchronize_slot(slot); });
 }
 
 ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,

@@ -106,3 +106,19 @@ class ShardedGGNN:
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
         ids, dists = self.engine.bf_query(query, k_gt, measure)
         return self._exchange(ids, dists, int(k_gt))
+
+    # batches in flight: the local search of batch i+1 is enqueued before batch i is exchanged, so
+    # the thin tail of a rank's 10k-wave launch, the all-gather and the merge all overlap with the
+    # next batch's traversal (every rank must call these in the same order)
+    def query_async(self, query, k_query, tau_query, max_iterations=400,
+                    measure=DistanceMeasure.Euclidean, slot=0):
+        """enqueue the local search of one batch; returns a ticket for `finish`"""
+        ids, dists = self.engine.query_async(query, k_query, tau_query, max_iterations, measure,
+                                             slot)
+        return (ids, dists, int(k_query), int(slot))
+
+    def finish(self, ticket):
+        """wait for the ticket's local search, exchange and merge: the global [Nq, K] result"""
+        ids, dists, k, slot = ticket
+        self.engine.synchronize(slot)
+        return self._exchange(ids, dists, k)

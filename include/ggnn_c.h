@@ -106,6 +106,8 @@ ggnn_status ggnn_query_async(ggnn_t* h, const void* query, uint64_t Nq, uint32_t
                              uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,
                              float* dists_out, uint32_t slot);
 ggnn_status ggnn_synchronize(ggnn_t* h);
+/* wait for the batches of one slot only (slots are taken modulo the number of streams, 4) */
+ggnn_status ggnn_synchronize_slot(ggnn_t* h, uint32_t slot);
 
 /* bfQuery ggnn.cuh:162-172, ggnn.cu:543-564 */
 ggnn_status ggnn_bf_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,

@@ -82,6 +82,8 @@ def test_bench_two_ranks_strong_scaling_line(tmp_path):
     assert abs(d["value"] - 600 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "8 shards x 20000" in d["config"]["workload"]
     assert d["recall_at_10"] > 0.95
+    pip = d["pipelined_batches"]
+    assert pip.get("results_equal_blocking") is True and pip["queries_per_s"] > 0, pip
     one = d["one_gpu_same_base"]
     assert one["recall_at_10"] > 0.95 and one["queries_per_s"] > 0
     assert abs(d["speedup_vs_one_gpu_same_base"] - d["value"] / one["queries_per_s"]) < 1e-9

@@ -32,6 +32,12 @@ def main():
     qd = torch.from_numpy(q).cuda()
     gt, gt_d = sh.bf_query(qd, K)
     ids, d = sh.query(qd, K, 0.8, 400)
+    # batches in flight: tickets finished in order give the blocking results
+    t0 = sh.query_async(qd, K, 0.8, 400, slot=0)
+    t1 = sh.query_async(qd, K, 0.8, 400, slot=1)
+    for t in (t0, t1):
+        a_ids, a_d = sh.finish(t)
+        assert torch.equal(a_ids, ids) and torch.equal(a_d, d)
     local_ids, local_d = sh.engine.query(qd, K, 0.8, 400)   # this rank's sorted [Nq, K*spg] rows
     gathered = [None] * world
     dist.all_gather_object(gathered, (local_ids.cpu().numpy(), local_d.cpu().numpy()))
