@@ -132,7 +132,7 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
                         const int32_t* translation, float criteria_half, const PS& ps)
 {
   const int lane = threadIdx.x;
-  cand = __shfl(cand, lane & 31);
+  cand = lower_half_to_both(cand);
   cand = sl.filter(cand, lds.known);
   const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
   const int nsurv = __popcll(surv);

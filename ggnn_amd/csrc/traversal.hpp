@@ -65,6 +65,31 @@ GGNN_DEV float lane_down1(float v)
   return __int_as_float(lane_down1(__float_as_int(v)));
 }
 
+// Cross-half exchange as ONE VALU instruction (gfx950 v_permlane32_swap) instead of an LDS
+// crossbar round trip (ds_bpermute): lower[i] / upper[i] = the value lanes i and i+32 hold, both
+// delivered to lanes i and i+32.
+GGNN_DEV void halves(int v, int& lower, int& upper)
+{
+  const auto r = __builtin_amdgcn_permlane32_swap(static_cast<unsigned>(v),
+                                                  static_cast<unsigned>(v), false, false);
+  lower = static_cast<int>(r[0]);
+  upper = static_cast<int>(r[1]);
+}
+// lanes j and j+32 <- the value of lane j (j < 32)
+GGNN_DEV int lower_half_to_both(int v)
+{
+  int lo, up;
+  halves(v, lo, up);
+  return lo;
+}
+// min over the two half-waves, lane by lane
+GGNN_DEV unsigned min_over_halves(unsigned v)
+{
+  int lo, up;
+  halves(static_cast<int>(v), lo, up);
+  return min(static_cast<unsigned>(lo), static_cast<unsigned>(up));
+}
+
 // sum over groups of LPR consecutive lanes; every lane of a group receives the group total
 template <int LPR>
 GGNN_DEV float group_sum(float v)
@@ -75,10 +100,18 @@ GGNN_DEV float group_sum(float v)
     v += dpp_f<0x141>(v);  // row_half_mirror
   if (LPR >= 16)
     v += dpp_f<0x140>(v);  // row_mirror
-  if (LPR >= 32)
-    v += __shfl_xor(v, 16);
-  if (LPR >= 64)
-    v += __shfl_xor(v, 32);
+  // rows of 16 / half-waves exchanged by v_permlane16_swap / v_permlane32_swap: one VALU
+  // instruction each instead of a ds_bpermute round trip (a + b in either order: same bits)
+  if (LPR >= 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false,
+                                                    false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if (LPR >= 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false,
+                                                    false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 
@@ -492,9 +525,7 @@ struct SortedList {
     t += 2;
     if (t < T)
       acc0 = fold(acc0, p[2 * t]);
-    const unsigned acc = min(acc0, acc1);
-    const unsigned other = static_cast<unsigned>(__shfl_xor(static_cast<int>(acc), 32));
-    return (min(acc, other) == 0u) ? kEmptyKey : cand;
+    return (min_over_halves(min(acc0, acc1)) == 0u) ? kEmptyKey : cand;
   }
 };
 
@@ -622,8 +653,7 @@ struct LdsList {
       const unsigned b = min(static_cast<unsigned>(e.z) ^ c, static_cast<unsigned>(e.w) ^ c);
       acc = min(acc, min(a, b));
     }
-    const unsigned other = static_cast<unsigned>(__shfl_xor(static_cast<int>(acc), 32));
-    return (min(acc, other) == 0u) ? kEmptyKey : cand;
+    return (min_over_halves(acc) == 0u) ? kEmptyKey : cand;
   }
 };
 
@@ -1101,7 +1131,7 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
                    HOOK&& after_filter = NoHook{})
 {
   const int lane = threadIdx.x;
-  cand = __shfl(cand, lane & 31);
+  cand = lower_half_to_both(cand);
   if (FILTER)
     cand = sl.filter(cand, lds.known);
   const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
