@@ -493,6 +493,17 @@ def run_single(args, device, ggnn):
                                    "dimension 24 / 32, i.i.d.): harder bases need more effort; "
                                    "the second point of each is tau 1.0 / 400 iterations",
                            "results": ds}
+    if not args.no_datasets:
+        # the reference's own four SIFT1M settings (sift1m_fvecs.py:19-30 / ggnn_benchmark.cpp:
+        # 196-200: tau 0.34 / 0.41 / 0.51 at 200 iterations, 0.64 at 400) and two higher-effort
+        # points on this synthetic base: recall against the exact ground truth, kernel rate
+        pts = {}
+        for tau, iters in ((0.34, 200), (0.41, 200), (0.51, 200), (0.64, 400), (0.9, 175), (1.0, 400)):
+            r = measure_point(eng, query, gt, args, 5, tau, iters)
+            ids_p, _ = eng.query(query, args.k, tau, iters)
+            r["c_at_1"] = (ids_p[:, 0] == gt[:, 0]).float().mean().item()
+            pts[f"tau={tau},iters={iters}"] = r
+        out["operating_points"] = pts
     if not args.no_scaling_reference:
         out["strong_scaling_one_gpu"] = scaling_reference(args, device, ggnn, max(5, args.steps // 2))
     if not args.no_cpu_baseline:
