@@ -133,7 +133,7 @@ query_kernel(const QueryArgs a)
   }
 }
 
-// Same kernel with the LDS-resident list (SORTED > 256, i.e. KQuery > 239).
+// Same kernel with the LDS-resident list (SORTED > 512, i.e. KQuery > 495).
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 __global__ void __launch_bounds__(kWave) query_kernel_lds(const QueryArgs a)
 {
@@ -234,8 +234,11 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   else if (sorted <= 256)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
+  else if (sorted <= 512)  // KQuery <= 495: eight list registers per lane
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 8, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
+                       stream, args);
   else {
-    // SORTED > 256: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
+    // SORTED > 512: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
     const size_t lds_big = (args.cache + sorted + WaveLds::extra_ints) * sizeof(int);
     GGNN_REQUIRE(lds_big <= 64 * 1024, GGNN_UNSUPPORTED, "cache too large for one workgroup");
     hipLaunchKernelGGL((query_kernel_lds<BaseT, LPR, NCH, MODE, PSC>), grid_for(args.Nq), dim3(kWave),

@@ -561,7 +561,8 @@ def test_bf_mfma_float_tolerance(ops, orc, measure, D):
 # larger K: four sorted-list registers per lane (KQuery <= 239, KBuild up to the reference's
 # effective limit), and arbitrary D through zero-padded rows in the engine
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("K,iters", [(120, 512), (200, 512), (239, 1024)])
+@pytest.mark.parametrize("K,iters", [(120, 512), (200, 512), (239, 1024), (240, 1024), (400, 1024),
+                                     (495, 2048), (496, 2048)])
 def test_query_large_k_exact(ops, orc, small_graph, K, iters):
     g = small_graph
     q = make_int_data(24, g["D"], 91)
