@@ -567,12 +567,12 @@ def run_sharded(args, device, ggnn, world, rank):
     # batch i is exchanged and merged); not part of `value`
     pipelined = None
     if not args.no_pipelined:
-        try:
-            tickets = [sharded.query_async(query, args.k, args.tau_query, args.max_iters, slot=0)]
-            sharded.finish(tickets.pop())
-            barrier()
+        pip, same, err = -1.0, False, None
+        try:  # informational only: never lose the main line over it
+            sharded.finish(sharded.query_async(query, args.k, args.tau_query, args.max_iters, slot=0))
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            last = None
+            tickets, last = [], None
             for i in range(args.steps):
                 tickets.append(sharded.query_async(query, args.k, args.tau_query, args.max_iters,
                                                    slot=i % 2))
@@ -580,18 +580,21 @@ def run_sharded(args, device, ggnn, world, rank):
                     last = sharded.finish(tickets.pop(0))
             while tickets:
                 last = sharded.finish(tickets.pop(0))
-            barrier()
-            pip = time.perf_counter() - t0
-            tp = torch.tensor([pip], dtype=torch.float64,
-                              device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            pip = float(tp.item()) / args.steps
+            torch.cuda.synchronize()
+            pip = (time.perf_counter() - t0) / args.steps
             same = bool(torch.equal(last[0], ids) and torch.equal(last[1], dists))
-            pipelined = {"batches_in_flight": 2, "ms_per_batch": pip * 1e3,
-                         "queries_per_s": args.n_query / pip,
-                         "results_equal_blocking": same}
-        except Exception as e:  # informational only: never lose the main line over it
-            pipelined = {"error": repr(e)}
+        except Exception as e:
+            err = repr(e)
+        # every rank takes part in this reduction whether or not its attempt worked
+        tp = torch.tensor([pip, 0.0 if err else 1.0], dtype=torch.float64,
+                          device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        worst = float(tp[0].item())
+        if err is None and worst > 0:
+            pipelined = {"batches_in_flight": 2, "ms_per_batch": worst * 1e3,
+                         "queries_per_s": args.n_query / worst, "results_equal_blocking": same}
+        else:
+            pipelined = {"error": err or "failed on another rank"}
     del sharded, eng, base
     torch.cuda.empty_cache()
 
