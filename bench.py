@@ -601,7 +601,10 @@ def run_sharded(args, device, ggnn, world, rank):
     # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
     one = None
     if rank == 0 and not args.no_scaling_reference:
-        one = scaling_reference(args, device, ggnn, max(5, args.steps // 2))
+        try:
+            one = scaling_reference(args, device, ggnn, max(5, args.steps // 2))
+        except Exception as e:  # e.g. not enough free memory next to another job: keep the line
+            one = {"error": repr(e)}
     barrier()
 
     if rank == 0:
@@ -627,10 +630,12 @@ def run_sharded(args, device, ggnn, world, rank):
             "graph_build_s_per_gpu": build_kernel_s, "graph_build_wall_s": build_wall_s,
             "query_kernel_ms_sum_over_local_shards": float(np.mean(kernel_ms)),
             "one_gpu_same_base": one,
-            "speedup_vs_one_gpu_same_base": (None if one is None else value / one["queries_per_s"]),
+            "speedup_vs_one_gpu_same_base": (None if not one or "queries_per_s" not in one
+                                             else value / one["queries_per_s"]),
             "pipelined_batches": pipelined,
             "pipelined_speedup_vs_one_gpu_same_base": (
-                None if one is None or not pipelined or "queries_per_s" not in pipelined
+                None if not one or "queries_per_s" not in one or not pipelined
+                or "queries_per_s" not in pipelined
                 else pipelined["queries_per_s"] / one["queries_per_s"]),
             "roofline": None, "cpu_baseline": None,
             "note": "N=1 of this command is the BASELINE single-shard configuration; the "
