@@ -27,14 +27,19 @@ for case in range(n_cases):
     tau = float(rng.choice([0.3, 0.6, 0.9, 1.5]))
     iters = int(rng.choice([50, 200, 256, 400, 600]))
     pre = bool(rng.integers(0, 2))
+    shards = int(rng.choice([1, 1, 2, 3, 4]))
+    N = N // shards * shards
     hi = 256
     base = rng.integers(0, hi, (N, D)).astype(np.uint8 if dtype == "u8" else np.float32)
     q = rng.integers(0, hi, (Nq, D)).astype(base.dtype)
-    tag = f"case {case}: {dtype} N={N} D={D} Nq={Nq} K={K} KB={KB} tau={tau} it={iters} pre={pre}"
+    tag = (f"case {case}: {dtype} N={N} D={D} Nq={Nq} K={K} KB={KB} tau={tau} it={iters} pre={pre} "
+           f"shards={shards}")
     try:
         eng = ggnn.GGNN()
         eng.set_base(base)
         eng.set_prescreen(pre)
+        if shards > 1:
+            eng.set_shard_size(N // shards)
         eng.build(KB, 0.5, 1)
         gt, gd = eng.bf_query(q, K)
         o_ids, o_d = orc.bf_query(base, q, K)
@@ -42,13 +47,36 @@ for case in range(n_cases):
         # ids may differ only where distances tie exactly AND data has duplicates; compare via dist
         same_ids = np.array_equal(gt.numpy(), o_ids)
         if K > N:
+            print(f"ok {tag} (bf only)", flush=True)
+            continue
+        if K > N // shards:
+            print(f"ok {tag} (bf only: K exceeds the shard) bf_d={ok_bf} bf_ids={same_ids}", flush=True)
+            bad += 0 if (ok_bf and same_ids) else 1
             continue
         ids, d = eng.query(q, K, tau, iters)
-        g = eng.get_graph(0)
-        oq_ids, oq_d = orc.query(base, q, g.graph[0].view.numpy(),
-                                 g.translation[3].view.numpy().reshape(-1),
-                                 g.nn1_stats.view.numpy().reshape(-1), K, tau, iters)
-        ok_q = np.array_equal(ids.numpy(), oq_ids) and np.array_equal(d.numpy(), oq_d)
+        n_s = N // shards
+        rows_i, rows_d = [], []
+        for sh in range(shards):
+            g = eng.get_graph(sh)
+            o = orc.query(base[sh * n_s:(sh + 1) * n_s], q, g.graph[0].view.numpy(),
+                          g.translation[3].view.numpy().reshape(-1),
+                          g.nn1_stats.view.numpy().reshape(-1), K, tau, iters)
+            rows_i.append(o[0] + sh * n_s)
+            rows_d.append(o[1])
+        if shards == 1:
+            oq_ids, oq_d = rows_i[0], rows_d[0]
+            ok_q = np.array_equal(ids.numpy(), oq_ids) and np.array_equal(d.numpy(), oq_d)
+        else:
+            # per-GPU sorted rows, first K of each (result_merger.cpp:62-73); ids at exactly
+            # tied distances may come from either shard
+            si, sd = orc.sort_shard_results(np.concatenate(rows_i, 1), np.concatenate(rows_d, 1))
+            oq_ids, oq_d = si[:, :K], sd[:, :K]
+            uniq = np.ones_like(oq_d, bool)
+            uniq[:, 1:] &= oq_d[:, 1:] != oq_d[:, :-1]
+            uniq[:, :-1] &= oq_d[:, :-1] != oq_d[:, 1:]
+            last_tied = sd[:, K - 1] == sd[:, min(K, sd.shape[1] - 1)] if sd.shape[1] > K else False
+            uniq[:, -1] &= ~np.asarray(last_tied)
+            ok_q = np.array_equal(d.numpy(), oq_d) and np.array_equal(ids.numpy()[uniq], oq_ids[uniq])
         status = "ok" if (ok_bf and same_ids and ok_q) else "MISMATCH"
         if status != "ok":
             bad += 1
