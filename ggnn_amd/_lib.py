@@ -84,6 +84,7 @@ SIGNATURES = {
     "ggnn_last_query_counters": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_set_collect_counters": (_int, [_vp, _int]),
     "ggnn_set_prescreen": (_int, [_vp, _int]),
+    "ggnn_set_build_hooks": (_int, [_vp, _vp, _u64, _int]),
     "ggnn_get_shard_layout": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_last_query_rows_read": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_set_log_level": (None, [_int]),

@@ -360,6 +360,17 @@ class GGNN:
         extension: same results, less memory traffic; costs N x D bytes per shard)."""
         self._check(lib().ggnn_set_prescreen(self._h, int(bool(enable))))
 
+    def set_build_hooks(self, rng=None, serial_sym=False):
+        """Deterministic build (see ggnn_set_build_hooks): `rng` = [3, N_shard] float32 uniform
+        (0, 1] numbers for the selection kernel, `serial_sym` = sym one point per launch in
+        ascending order.  Used to compare a whole build with a CPU restatement bit for bit."""
+        if rng is None:
+            self._check(lib().ggnn_set_build_hooks(self._h, None, 0, int(bool(serial_sym))))
+            return
+        arr = np.ascontiguousarray(np.asarray(rng, dtype=np.float32))
+        self._check(lib().ggnn_set_build_hooks(self._h, arr.ctypes.data, arr.size,
+                                               int(bool(serial_sym))))
+
     def last_exchange(self):
         """how the last query combined per-GPU results: "none", "rccl" or "copy" """
         return lib().ggnn_last_exchange(self._h).decode()

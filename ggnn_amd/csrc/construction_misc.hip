@@ -296,15 +296,21 @@ void launch_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t* sym_buf
 // Reference: computeNN1Stats + divide, graph_construction.cu:381-393,79-83 (cub::DeviceReduce,
 // summation order unpinned).  Two-pass deterministic tree reduction.
 // ---------------------------------------------------------------------------------------------
+// The sum is accumulated in float64: cub::DeviceReduce's float order is third-party and unpinned
+// (SURVEY 8c), and a float64 sum of N <= 2^31 floats is order-insensitive to ~N * 2^-53 relative,
+// far below one float32 ulp -- every summation order (this tree, the oracle's serial loop) rounds
+// to the same float mean.  The kernel streams N * 4 bytes; the wider adds are free.
+// scratch: [blocks] double sums, then [blocks] float maxima.
 __global__ void __launch_bounds__(256) nn1_partial_kernel(const float* v, uint32_t N,
-                                                          float* scratch)
+                                                          double* sums, float* maxima)
 {
-  __shared__ float s_sum[256];
+  __shared__ double s_sum[256];
   __shared__ float s_max[256];
-  float sum = 0.f, mx = -inf_f();
+  double sum = 0.0;
+  float mx = -inf_f();
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
     const float x = v[i];
-    sum += x;
+    sum += static_cast<double>(x);
     mx = fmaxf(mx, x);
   }
   s_sum[threadIdx.x] = sum;
@@ -318,20 +324,21 @@ __global__ void __launch_bounds__(256) nn1_partial_kernel(const float* v, uint32
     __syncthreads();
   }
   if (!threadIdx.x) {
-    scratch[blockIdx.x] = s_sum[0];
-    scratch[gridDim.x + blockIdx.x] = s_max[0];
+    sums[blockIdx.x] = s_sum[0];
+    maxima[blockIdx.x] = s_max[0];
   }
 }
 
-__global__ void __launch_bounds__(256) nn1_final_kernel(const float* scratch, uint32_t blocks,
-                                                        uint32_t N, float* out)
+__global__ void __launch_bounds__(256) nn1_final_kernel(const double* sums, const float* maxima,
+                                                        uint32_t blocks, uint32_t N, float* out)
 {
-  __shared__ float s_sum[256];
+  __shared__ double s_sum[256];
   __shared__ float s_max[256];
-  float sum = 0.f, mx = -inf_f();
+  double sum = 0.0;
+  float mx = -inf_f();
   for (uint32_t i = threadIdx.x; i < blocks; i += 256) {
-    sum += scratch[i];
-    mx = fmaxf(mx, scratch[blocks + i]);
+    sum += sums[i];
+    mx = fmaxf(mx, maxima[i]);
   }
   s_sum[threadIdx.x] = sum;
   s_max[threadIdx.x] = mx;
@@ -344,7 +351,8 @@ __global__ void __launch_bounds__(256) nn1_final_kernel(const float* scratch, ui
     __syncthreads();
   }
   if (!threadIdx.x) {
-    out[0] = s_sum[0] / static_cast<float>(N);  // divide<<<1,1>>>: only element 0
+    // divide<<<1,1>>>: only element 0
+    out[0] = static_cast<float>(s_sum[0] / static_cast<double>(N));
     out[1] = s_max[0];
   }
 }
@@ -353,8 +361,13 @@ void launch_nn1_stats(const float* nn1, uint32_t N, float* scratch, float* out, 
 {
   GGNN_REQUIRE(N > 0, GGNN_INVALID_ARGUMENT, "nn1 statistics of an empty buffer");
   const uint32_t blocks = std::min(kStatsBlocks, (N + 255) / 256);
-  hipLaunchKernelGGL(nn1_partial_kernel, dim3(blocks), dim3(256), 0, stream, nn1, N, scratch);
-  hipLaunchKernelGGL(nn1_final_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, N, out);
+  GGNN_REQUIRE(reinterpret_cast<uintptr_t>(scratch) % 8 == 0, GGNN_INVALID_ARGUMENT,
+               "nn1 statistics scratch must be 8-byte aligned");
+  double* sums = reinterpret_cast<double*>(scratch);
+  float* maxima = scratch + 2 * kStatsBlocks;
+  hipLaunchKernelGGL(nn1_partial_kernel, dim3(blocks), dim3(256), 0, stream, nn1, N, sums, maxima);
+  hipLaunchKernelGGL(nn1_final_kernel, dim3(1), dim3(256), 0, stream, sums, maxima, blocks, N,
+                     out);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 

@@ -303,6 +303,11 @@ struct ggnn_handle {
   bool prescreen{std::getenv("GGNN_PRESCREEN") == nullptr ||
                  std::string(std::getenv("GGNN_PRESCREEN")) != "0"};
 
+  // deterministic-build hooks (ggnn_set_build_hooks): injected selection random numbers
+  // ([layers-1][N_shard], shard-local) and sym launched one point at a time in ascending order
+  std::vector<float> hook_rng;
+  bool hook_serial_sym{false};
+
   // base as handed over by the caller
   const void* base_src{nullptr};
   ggnn_location base_loc{GGNN_CPU};
@@ -550,7 +555,7 @@ struct ggnn_handle {
     // scratch (GraphBuffer, graph_buffer.cu:38-81); not overlapped -- HBM is plentiful
     DeviceBuffer nn1_dist(static_cast<size_t>(N) * 4), graph_buffer(static_cast<size_t>(N) * K * 4),
         rng(static_cast<size_t>(N) * 4), sym_buffer(static_cast<size_t>(N) * KF * 4),
-        sym_atomic(static_cast<size_t>(N) * 4), stats_scratch(2 * kStatsBlocks * 4);
+        sym_atomic(static_cast<size_t>(N) * 4), stats_scratch(3 * kStatsBlocks * 4);
     ctx.build_ms = 0.f;
     uint64_t rng_calls = static_cast<uint64_t>(ctx.first_shard) << 16;
 
@@ -606,7 +611,15 @@ struct ggnn_handle {
                            stream);
       };
       auto do_select = [&](uint32_t layer) {
-        launch_uniform(rng.as<float>(), cfg.Ns[layer], 1234ull, rng_calls++, stream);
+        if (!hook_rng.empty()) {
+          GGNN_REQUIRE(hook_rng.size() >= static_cast<size_t>(layer + 1) * N, GGNN_INVALID_ARGUMENT,
+                       "build hooks: rng needs (layers - 1) * N_shard numbers");
+          GGNN_HIP_CHECK(hipMemcpyAsync(rng.p, hook_rng.data() + static_cast<size_t>(layer) * N,
+                                        static_cast<size_t>(cfg.Ns[layer]) * 4,
+                                        hipMemcpyHostToDevice, stream));
+        }
+        else
+          launch_uniform(rng.as<float>(), cfg.Ns[layer], 1234ull, rng_calls++, stream);
         launch_select(cfg, layer, nn1_dist.as<float>(), rng.as<float>(), sh.translation,
                       sh.selection, stream);
       };
@@ -642,7 +655,18 @@ struct ggnn_handle {
           s.ps_params = sh.ps_params.as<float>();
           s.ps_Dc = prescreen_code_dim(pad_D);
         }
-        launch_sym(s, stream);
+        if (hook_serial_sym) {
+          // the reference's sym races through atomics and cross-block reads of sym_buffer
+          // (sym_query_layer.cu:102-104 vs :133-136); one point per launch in ascending order is
+          // the one schedule that is comparable with a CPU restatement
+          for (uint32_t n = 0; n < cfg.Ns[layer]; ++n) {
+            s.first_n = n;
+            s.count = 1;
+            launch_sym(s, stream);
+          }
+        }
+        else
+          launch_sym(s, stream);
         launch_sym_buffer_merge(K, cfg.Ns[layer], sym_buffer.as<int32_t>(),
                                 sym_atomic.as<uint32_t>(), layer_graph(layer), stream);
       };
@@ -1443,6 +1467,16 @@ ggnn_status ggnn_build(ggnn_t* h, uint32_t k_build, float tau_build,
   return guarded(h, [&] { h->build(k_build, tau_build, refinement_iterations, measure); });
 }
 
+ggnn_status ggnn_set_build_hooks(ggnn_t* h, const float* rng, uint64_t n_rng, int serial_sym)
+{
+  GGNN_NEED_HANDLE(h);
+  return guarded(h, [&] {
+    GGNN_REQUIRE(rng != nullptr || n_rng == 0, GGNN_INVALID_ARGUMENT, "rng is null");
+    h->hook_rng.assign(rng, rng + n_rng);
+    h->hook_serial_sym = serial_sym != 0;
+  });
+}
+
 ggnn_status ggnn_store(ggnn_t* h)
 {
   GGNN_NEED_HANDLE(h);
@@ -1782,7 +1816,7 @@ ggnn_status ggnn_op_sym_buffer_merge(uint32_t KBuild, uint32_t N_layer, int32_t*
 
 size_t ggnn_nn1_stats_scratch_floats(void)
 {
-  return 2 * kStatsBlocks;
+  return 3 * kStatsBlocks;
 }
 
 ggnn_status ggnn_op_nn1_stats(const float* nn1_dist_buffer, uint32_t N, float* scratch,

@@ -158,6 +158,15 @@ ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uin
  * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
  * environment variable GGNN_PRESCREEN=0 turns the default off. */
 ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable);
+/* Deterministic build (no reference counterpart; the reference's build is not reproducible:
+ * cuRAND stream graph_construction.cu:96-102,168-169, atomics and cross-block reads in sym
+ * sym_query_layer.cu:102-104,124-141).  `rng` (host, may be null with n_rng = 0): uniform (0,1]
+ * numbers for the selection kernel, [3][N_shard], layer l of every shard reads rng[l * N_shard
+ * + n] instead of the engine's generator; `serial_sym` != 0 launches the sym kernel one point
+ * at a time in ascending order.  With both, ggnn_build follows one fixed serialisation of
+ * GraphConstructionImpl::build/refine (graph_construction.cu:128-147) that a CPU restatement can
+ * be compared with bit for bit.  Slow; off by default. */
+ggnn_status ggnn_set_build_hooks(ggnn_t* h, const float* rng, uint64_t n_rng, int serial_sym);
 /* shard layout chosen by ggnn_build / ggnn_load (GGNNImpl::prepare, ggnn.cu:154-203): total
  * number of shards, shards per GPU (the width factor of results returned on the GPU,
  * ggnn.cu:299-306) and points per shard.  GGNN_INVALID_STATE without a graph. */

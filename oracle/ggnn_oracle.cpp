@@ -1192,22 +1192,18 @@ void orc_sym_buffer_merge(uint32_t KBuild, uint32_t Nlayer, const int32_t* sym_b
 }
 
 // Row N: src/ggnn/construction/graph_construction.cu:381-393, 79-83.
-// cub::DeviceReduce's summation order is third-party and unpinned; a pairwise float tree is
-// used here (error bound of the same class) -- compare with tolerance.
+// cub::DeviceReduce's float summation order is third-party and unpinned; the sum is taken in
+// float64 here (order-insensitive far below one float32 ulp), so that any summation order --
+// this serial loop, the engine's tree -- rounds to the same float mean.
 void orc_nn1_stats(const float* v, uint32_t N, float* out)
 {
-  std::vector<float> a(v, v + N);
-  uint32_t n = N;
-  while (n > 1) {
-    const uint32_t h = (n + 1) / 2;
-    for (uint32_t i = 0; i + h < n; ++i)
-      a[i] = a[i] + a[i + h];
-    n = h;
-  }
-  float mx = v[0];
-  for (uint32_t i = 1; i < N; ++i)
+  double sum = 0.0;
+  float mx = N ? v[0] : 0.f;
+  for (uint32_t i = 0; i < N; ++i) {
+    sum += static_cast<double>(v[i]);
     mx = std::max(mx, v[i]);
-  out[0] = (N ? a[0] : 0.f) / static_cast<float>(N);
+  }
+  out[0] = static_cast<float>(sum / static_cast<double>(N));
   out[1] = mx;
 }
 

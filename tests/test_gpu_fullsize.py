@@ -146,3 +146,111 @@ def test_uint8_shard_beyond_4gib():
         cand = gt[n].long()
         dd = ((base[cand].float() - query[n].float()) ** 2).sum(1)
         assert torch.equal(dd, gt_d[n])
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def _shard_case(orc, N, D, dtype, expect, tau, iters, nq=10_000, n_oracle=100, check_prescreen=False):
+    """One BASELINE shard at its defining size: layout equal to SURVEY 8(a) row L, build, recall
+    against the certified exact bf_query, oracle traversal over the GPU-built graph."""
+    import ggnn_amd as ggnn
+    from bench import synthetic
+    dev = torch.device("cuda", 0)
+    K = 10
+    base = torch.empty((N, D), dtype=dtype, device=dev)
+    for lo in range(0, N, 5_000_000):
+        hi = min(N, lo + 5_000_000)
+        base[lo:hi] = synthetic("lowrank16", hi - lo, D, 1234 + lo, dev).to(dtype)
+    query = synthetic("lowrank16", nq, D, 4321, dev).to(dtype)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 2)
+    gt, gt_d = eng.bf_query(query, K)
+    assert eng.last_bf_query_rescanned() <= nq // 100
+    eng.set_collect_counters(True)
+    ids, d = eng.query(query, K, tau, iters)
+    cnt = eng.last_query_counters()
+    rec = recall_at_k(ids, gt)
+    assert rec >= 0.99, rec
+    if check_prescreen:
+        rows = eng.last_query_rows_read()
+        assert rows["code_rows"] > 0
+        eng.set_prescreen(False)
+        ids2, d2 = eng.query(query, K, tau, iters)
+        assert eng.last_query_counters() == cnt
+        assert torch.equal(ids, ids2) and torch.equal(d, d2)
+        eng.set_prescreen(True)
+    # exact ground truth spot check with 64-bit row indices
+    for n in (0, nq // 2, nq - 1):
+        cand = gt[n].long()
+        dd = ((base[cand].float() - query[n].float()) ** 2).sum(1)
+        assert torch.equal(dd, gt_d[n])
+    # layout: SURVEY 8(a) row L (values the survey obtained from the reference's graph_config.cpp)
+    view = _graph_view(eng)
+    cfg = view.config.as_dict()
+    for key, val in expect.items():
+        assert cfg[key] == val, (key, cfg[key], val)
+    # oracle traversal (needs the rows and layer 0 of the graph on the host)
+    need_gb = (N * D * base.element_size() + N * 24 * 4) / 1e9
+    if _mem_available_gb() < 2.5 * need_gb + 16:
+        pytest.skip(f"host memory too small for the oracle part ({need_gb:.0f} GB of rows + graph)")
+    base_h = base.cpu().numpy()
+    graph0 = torch.empty((N, 24), dtype=torch.int32)
+    _copy_d2h(graph0, view.graph, N * 24 * 4)
+    ST = cfg["STs_offsets"][3]
+    start = torch.empty(cfg["Ns"][3], dtype=torch.int32)
+    _copy_d2h(start, view.translation + ST * 4, cfg["Ns"][3] * 4)
+    stats = torch.empty(2, dtype=torch.float32)
+    _copy_d2h(stats, view.nn1_stats, 8)
+    q_h = query[:n_oracle].cpu().numpy()
+    o_ids, o_d, o_nd, o_np = orc.query(base_h, q_h, graph0.numpy(), start.numpy(), stats.numpy(),
+                                       K, tau, iters, counters=True)
+    assert np.array_equal(ids[:n_oracle].cpu().numpy(), o_ids)
+    assert np.array_equal(d[:n_oracle].cpu().numpy(), o_d)
+    eng.query(query[:n_oracle].contiguous(), K, tau, iters)
+    c = eng.last_query_counters()
+    assert c["n_dist"] == int(o_nd.sum()) and c["n_pop"] == int(o_np.sum())
+
+
+def _graph_view(eng):
+    import ctypes as C
+    from ggnn_amd import _lib
+    view = _lib.GraphView()
+    _lib.check(_lib.lib().ggnn_get_graph(eng._h, 0, C.byref(view)), eng._h)
+    return view
+
+
+def _copy_d2h(dst, src_ptr, nbytes):
+    """device pointer of the engine's graph pool -> pinned-free host tensor, without the full
+    get_graph() copy (12 GB for the C5 shard)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    assert hip.hipMemcpy(dst.data_ptr(), src_ptr, nbytes, 2) == 0   # hipMemcpyDeviceToHost
+
+
+def test_deep100m_shard_full_size(orc):
+    """configs[3]: one of the 8 shards of DEEP100M, 12.5M x 96 f32.  G = 73 with SG = 0 and
+    SG_off = 32: only the first 32 of each 73 lower segments promote a point (graph_config.cpp
+    :94-97), a selection layout no smaller test reaches."""
+    _shard_case(orc, 12_500_000, 96, torch.float32,
+                dict(G=73, S=32, S0=32, S0_off=51_456, SG=0, SG_off=32, N_all=12_672_896),
+                1.0, 400, check_prescreen=True)
+
+
+def test_sift1b_shard_full_size(orc):
+    """configs[4]: one of the 8 shards of SIFT1B, 125M x 128 uint8 (16 GB of rows, 12 GB of
+    graph): G = 157, SG = 0, every index path beyond 2^32 bytes."""
+    _shard_case(orc, 125_000_000, 128, torch.uint8,
+                dict(G=157, S=32, S0=32, S0_off=1_163_424, SG=0, SG_off=32, N_all=125_793_824),
+                1.5, 400)
