@@ -18,13 +18,17 @@ queries/s (Nq / T), not shard-searches; the same line carries the one-GPU figure
 (all 8 shards resident on rank 0's GPU, measured in the same run) and the speed-up over it.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the resource that binds the query kernel (VALU issue, from the committed SQ
-                  counters of this workload) next to its byte rates (algorithmic / measured)
+  roofline     -- SURVEY 8(d): the query kernel's own algorithmic bytes per launch (from its live
+                  work counters) / its live HIP-event duration / the 8 TB/s HBM peak; the
+                  reference algorithm's bytes (n_dist x 4D, what the kernel avoids moving), the
+                  measured fabric traffic and the VALU-issue fraction (committed PMC passes, used
+                  only while the kernel sources still match them) are named secondaries
   cpu_baseline -- the CPU oracle (a port of the reference algorithm; the reference has no CPU
                   path) timed on a bounded sample on this box's host cores (N=1, rank 0 only)
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -39,9 +43,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CLOCK_HZ = 2.4e9          # nominal engine clock; SQ cycle counters tick once per 4 clocks
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
 F32_MFMA_PEAK = 157.3e12  # dense f32 MFMA
+I8_MFMA_PEAK = 3944e12    # int8 MFMA: measured ceiling >= 3944 TOPS (MI355X_MICROARCH.md, no spec figure)
 TOTAL_SHARDS = 8          # fixed base of the multi-GPU (strong scaling) series
 
 
@@ -71,6 +75,24 @@ def synthetic(kind, n, d, seed, device):
                 out[lo:hi].round_().clamp_(0, 255)
         return out
     raise ValueError(kind)
+
+
+def engine_clock_hz(device):
+    """engine clock the device reports (kHz -> Hz); SQ cycle counters tick once per 4 clocks"""
+    return float(torch.cuda.get_device_properties(device).clock_rate) * 1e3
+
+
+KERNEL_SOURCES = ("traversal.hpp", "query.hip", "common.hpp", "prescreen.hip")
+
+
+def kernel_source_sha():
+    """fingerprint of the traversal kernel sources: committed counter summaries carry the one
+    they were collected with and are ignored once it no longer matches"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "ggnn_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def recall_at_k(ids, gt):
@@ -115,7 +137,9 @@ def cpu_baseline(base, query, k, graph, cfg, stats, tau, iters, budget_s=12.0):
 
 
 def workload_string(args):
-    return (f"{args.dataset} SIFT1M-shaped {args.n_base}x{args.dim} f32 per GPU, "
+    shape = "SIFT1M-shaped " if (args.n_base, args.dim) == (1_000_000, 128) else ""
+    measure = "" if args.measure == "l2" else ", cosine"
+    return (f"{args.dataset} {shape}{args.n_base}x{args.dim} {args.dtype} per GPU{measure}, "
             f"{args.n_query} queries, k={args.k}, k_build={args.k_build}, "
             f"tau_build={args.tau_build}, refine={args.refine}, "
             f"tau_query={args.tau_query}, max_iterations={args.max_iters}")
@@ -131,17 +155,17 @@ def _latest_profile(suffix, args):
             continue
         if doc.get("workload") == workload_string(args):
             doc["_file"] = os.path.relpath(f, ROOT)
+            doc["_stale"] = doc.get("kernel_source_sha") != kernel_source_sha()
             return doc
     return None
 
 
 def _query_kernel_entry(doc, prescreened):
-    for name, c in doc["kernels"].items():
-        if "query_kernel" not in name or "bf_query" in name:
-            continue
-        if ("NoPrescreen" in name) == prescreened:
-            continue
-        return name, c
+    cands = [(name, c) for name, c in doc["kernels"].items()
+             if "query_kernel" in name and "bf_query" not in name]
+    for name, c in cands:
+        if ("NoPrescreen" in name) != prescreened:
+            return name, c
     return None, None
 
 
@@ -151,7 +175,7 @@ def pmc_traffic(args, prescreened):
     as MI355X_MICROARCH.md prescribes (KB units; FETCH_SIZE x2 on gfx950 for 16 B/lane loads).
     Only valid for the default workload; otherwise null."""
     doc = _latest_profile("_pmc_hbm.json", args)
-    if not doc:
+    if not doc or doc["_stale"]:
         return None
     _, c = _query_kernel_entry(doc, prescreened)
     if not c or "FETCH_SIZE" not in c:
@@ -164,47 +188,146 @@ def pmc_sq(args, prescreened):
     """SQ counters of the query kernel from the committed profile of this workload"""
     doc = _latest_profile("_pmc_sq.json", args)
     if not doc:
-        return None, None
+        return None, None, "no committed SQ counter pass for this workload"
+    if doc["_stale"]:
+        return None, doc["_file"], ("the kernel sources changed since this pass was collected "
+                                    "(kernel_source_sha differs): re-run scripts/profile_round.sh")
     name, c = _query_kernel_entry(doc, prescreened)
-    return (c, doc["_file"]) if c else (None, None)
+    if not c:
+        return None, doc["_file"], "the pass holds no entry for this kernel variant"
+    c = dict(c, _kernel=name)
+    return c, doc["_file"], None
 
 
-def measure_point(eng, query, gt, args, steps, tau=None, iters=None):
+def _measure(args):
+    import ggnn_amd as ggnn
+    return ggnn.DistanceMeasure.Cosine if args.measure == "cosine" else ggnn.DistanceMeasure.Euclidean
+
+
+def make_data(args, kind, n, seed, device):
+    x = synthetic(kind, n, args.dim, seed, device)
+    return x.to(torch.uint8) if args.dtype == "u8" else x
+
+
+def measure_point(eng, query, gt, args, steps, tau=None, iters=None, warm=2):
     """kernel time (HIP events inside the engine) and recall of one operating point"""
     tau = args.tau_query if tau is None else tau
     iters = args.max_iters if iters is None else iters
-    for _ in range(2):
-        eng.query(query, args.k, tau, iters)
+    m = _measure(args)
+    for _ in range(warm):
+        eng.query(query, args.k, tau, iters, m)
     ms = []
     for _ in range(steps):
-        ids, _ = eng.query(query, args.k, tau, iters)
+        ids, _ = eng.query(query, args.k, tau, iters, m)
         ms.append(eng.last_timing_ms()["query_ms"])
-    m = float(np.mean(ms))
-    return {"query_kernel_ms": m, "queries_per_s": query.shape[0] / (m * 1e-3),
+    t = float(np.mean(ms))
+    return {"query_kernel_ms": t, "queries_per_s": query.shape[0] / (t * 1e-3),
             "recall_at_10": recall_at_k(ids, gt)}
 
 
-def dataset_sweep(args, device, ggnn):
-    """the same operating point on other synthetic bases (the headline dataset is the easiest):
-    recall and query-kernel rate per dataset, each with its own exact ground truth"""
+SEARCH_TAUS = (0.5, 0.64, 0.8, 0.9, 1.0, 1.2, 1.5, 2.0, 2.5)
+SEARCH_ITERS = (100, 175, 250, 400, 600, 1000, 1500, 2000)
+
+
+def cheapest_point_at_recall(eng, query, gt, args, target=0.99):
+    """BASELINE's metric is queries/s AT recall@10 >= 0.99: the fastest (tau_query,
+    max_iterations) of a bounded grid that reaches the target on this base, against its own exact
+    ground truth.  The kernel time grows with both parameters, so rows of the grid are left as
+    soon as a point is slower than the best one found."""
+    best, top, tried = None, None, 0
+    for iters in SEARCH_ITERS:
+        for tau in SEARCH_TAUS:
+            r = measure_point(eng, query, gt, args, 2, tau, iters, warm=1)
+            tried += 1
+            r.update(tau_query=tau, max_iterations=iters)
+            if top is None or r["recall_at_10"] > top["recall_at_10"]:
+                top = r
+            if best is not None and r["query_kernel_ms"] >= best["query_kernel_ms"]:
+                break       # larger tau in this row only costs more
+            if r["recall_at_10"] >= target:
+                best = r
+                break
+    if best is not None:
+        tau, iters = best["tau_query"], best["max_iterations"]
+        best = measure_point(eng, query, gt, args, 5, tau, iters)
+        best.update(tau_query=tau, max_iterations=iters)
+    return best, top, tried
+
+
+def recall_target_sweep(args, device, ggnn, own_eng, own_query, own_gt):
+    """queries/s at recall@10 >= 0.99 per synthetic base (16 / 24 / 32-dimensional latent with
+    integer values, and the 16-dimensional one with genuinely fractional float32 values, whose
+    pre-screen codes are lossy), each with its own graph, exact ground truth and operating point"""
     out = {}
-    for kind in ("lowrank16", "lowrank24", "lowrank32", "iid"):
-        if kind == args.dataset:
+    for kind in ("lowrank16", "lowrank24", "lowrank32", "lowrankf16"):
+        if args.dtype == "u8" and kind == "lowrankf16":
             continue
-        base = synthetic(kind, args.n_base, args.dim, 1234, device)
-        query = synthetic(kind, args.n_query, args.dim, 4321, device)
-        eng = ggnn.GGNN()
-        eng.set_base_reference(base)
-        eng.set_return_results_on_gpu(True)
-        eng.build(args.k_build, args.tau_build, args.refine)
-        gt, _ = eng.bf_query(query, args.k)
-        r = measure_point(eng, query, gt, args, 5)
-        r["graph_build_s"] = eng.last_timing_ms()["build_ms"] / 1000.0
-        # a higher-effort point as well: where the recall of the harder bases goes
-        r["tau1.0_iters400"] = measure_point(eng, query, gt, args, 3, 1.0, 400)
+        if kind == args.dataset:
+            eng, query, gt, build_s = own_eng, own_query, own_gt, None
+        else:
+            base = make_data(args, kind, args.n_base, 1234, device)
+            query = make_data(args, kind, args.n_query, 4321, device)
+            eng = ggnn.GGNN()
+            eng.set_base_reference(base)
+            eng.set_return_results_on_gpu(True)
+            eng.build(args.k_build, args.tau_build, args.refine, _measure(args))
+            build_s = eng.last_timing_ms()["build_ms"] / 1000.0
+            gt, _ = eng.bf_query(query, args.k, _measure(args))
+        r = {"same_settings_as_headline": measure_point(eng, query, gt, args, 3)}
+        if build_s is not None:
+            r["graph_build_s"] = build_s
+        best, top, tried = cheapest_point_at_recall(eng, query, gt, args)
+        r["grid_points_tried"] = tried
+        if best is not None:
+            r["at_recall_0.99"] = best
+        else:
+            r["at_recall_0.99"] = None
+            r["not_reached_best"] = top
         out[kind] = r
-        del eng, base, query
-        torch.cuda.empty_cache()
+        if kind != args.dataset:
+            del eng, base, query, gt
+            torch.cuda.empty_cache()
+    return out
+
+
+def bf_block(args, bf_ms, rescanned):
+    """exact brute force (the recall ground truth) against the matrix-core peak of its dtype"""
+    ops_ = 2.0 * args.n_query * args.n_base * args.dim
+    if args.dtype == "u8" and args.measure == "l2" and args.dim <= 128:
+        kernel, peak, unit = "bf_mfma_i8_kernel (v_mfma_i32_32x32x32_i8), exact integers", I8_MFMA_PEAK, "TOPS"
+    else:
+        kernel, peak, unit = ("bf_mfma_kernel (v_mfma_f32_32x32x2_f32) + certified exact re-rank",
+                              F32_MFMA_PEAK, "TFLOP/s")
+    return {"ms": bf_ms, "kernel": kernel, "rate": ops_ / (bf_ms * 1e-3) / 1e12, "unit": unit,
+            "peak": peak / 1e12, "mfma_frac_of_peak": ops_ / (bf_ms * 1e-3) / peak,
+            "note": "end to end (norms, tile kernel, re-rank / certificate)",
+            "queries_rescanned_by_the_exact_scan": rescanned}
+
+
+def sift1m_real(directory, ggnn, device):
+    """$GGNN_SIFT1M_DIR/sift_base.fvecs + sift_query.fvecs (+ sift_groundtruth.ivecs): the
+    reference's four published settings (examples/python/sift1m_fvecs.py:19-30) next to their
+    targets, through the engine's own fvecs loader"""
+    base = ggnn.FloatDataset.load(os.path.join(directory, "sift_base.fvecs"))
+    query = ggnn.FloatDataset.load(os.path.join(directory, "sift_query.fvecs"))
+    b = base.view.to(device)
+    q = query.view.to(device)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(b)
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 2)
+    gt, _ = eng.bf_query(q, 10)
+    out = {"N": int(b.shape[0]), "Nq": int(q.shape[0]),
+           "graph_build_s": eng.last_timing_ms()["build_ms"] / 1e3, "points": {}}
+    for tau, iters, target in ((0.34, 200, "c@1 ~0.90"), (0.41, 200, "c@1 ~0.95"),
+                               (0.51, 200, "c@1 ~0.99"), (0.64, 400, "c@10 ~0.99")):
+        for _ in range(3):
+            ids, _ = eng.query(q, 10, tau, iters)
+        ms = eng.last_timing_ms()["query_ms"]
+        out["points"][f"tau={tau},iters={iters}"] = {
+            "published_target": target, "c_at_1": (ids[:, 0] == gt[:, 0]).float().mean().item(),
+            "c_at_10": recall_at_k(ids, gt), "query_kernel_ms": ms,
+            "queries_per_s": q.shape[0] / (ms * 1e-3)}
     return out
 
 
@@ -260,10 +383,35 @@ def build_roofline(args, eng, base):
     return out
 
 
-def scaling_reference(args, device, ggnn, steps):
-    """the strong-scaling series' one-GPU point: all TOTAL_SHARDS shards resident on this GPU"""
-    base = torch.cat([synthetic(args.dataset, args.n_base, args.dim, 1234 + s, device)
-                      for s in range(TOTAL_SHARDS)])
+def big_base(args, n_rows, seed0, device):
+    """n_rows synthetic rows generated in chunks of one shard (seed per shard, so that a shard
+    holds the same rows whichever rank or process generates it)"""
+    shards = n_rows // args.n_base
+    base = torch.empty((n_rows, args.dim), dtype=torch.float32, device=device)
+    for s_ in range(shards):
+        lo = s_ * args.n_base
+        for c in range(0, args.n_base, 5_000_000):
+            hi = min(args.n_base, c + 5_000_000)
+            base[lo + c:lo + hi] = synthetic(args.dataset, hi - c, args.dim,
+                                             1234 + 1000 * (seed0 + s_) + c // 5_000_000, device)
+    return base
+
+
+def timed(fn, steps, sync):
+    """wall time per call of fn() over `steps` calls, bracketed by sync()"""
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def one_gpu_reference(args, device, ggnn, steps):
+    """the one-GPU point of the strong-scaling series: all TOTAL_SHARDS shards of the SAME base
+    resident on this GPU (the reference would need its GPU<->CPU swapping or the 8 GPUs).
+    Blocking 10k-query calls, a saturating 100k-query batch and two batches in flight."""
+    base = big_base(args, TOTAL_SHARDS * args.n_base, 0, device)
     query = synthetic(args.dataset, args.n_query, args.dim, 4321, device)
     eng = ggnn.GGNN()
     eng.set_base_reference(base)
@@ -272,47 +420,73 @@ def scaling_reference(args, device, ggnn, steps):
     eng.build(args.k_build, args.tau_build, args.refine)
     build_s = eng.last_timing_ms()["build_ms"] / 1000.0
     gt, _ = eng.bf_query(query, args.k)
-    from ggnn_amd import ops
+    k = args.k
 
-    def step():
-        ids, dists = eng.query(query, args.k, args.tau_query, args.max_iters)
+    def step(q=query):
+        ids, dists = eng.query(q, k, args.tau_query, args.max_iters)
         # results on the GPU are the sorted [Nq, K * shards] rows: the answer is their head
-        return ids[:, :args.k], dists[:, :args.k]
+        return ids[:, :k], dists[:, :k]
 
     for _ in range(2):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ids, _ = step()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+    el, (ids, _) = timed(step, steps, torch.cuda.synchronize)
     out = {"workload": f"{TOTAL_SHARDS} resident shards x {args.n_base} points on ONE GPU "
                        f"({TOTAL_SHARDS * args.n_base} x {args.dim} f32), {args.n_query} queries",
            "queries_per_s": args.n_query / el, "ms_per_step": el * 1e3,
            "recall_at_10": recall_at_k(ids.contiguous(), gt), "graph_build_s": build_s}
+    try:
+        big = synthetic(args.dataset, 10 * args.n_query, args.dim, 9876, device)
+        step(big)
+        el_b, _ = timed(lambda: step(big), max(2, steps // 3), torch.cuda.synchronize)
+        out["saturated_batch"] = {"n_query": int(big.shape[0]), "ms_per_step": el_b * 1e3,
+                                  "queries_per_s": big.shape[0] / el_b}
+        del big
+        eng.query_async(query, k, args.tau_query, args.max_iters, slot=0)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.query_async(query, k, args.tau_query, args.max_iters, slot=i % 2)
+        eng.synchronize()
+        el_p = (time.perf_counter() - t0) / steps
+        out["pipelined_batches"] = {"batches_in_flight": 2, "ms_per_batch": el_p * 1e3,
+                                    "queries_per_s": args.n_query / el_p}
+    except Exception as e:   # secondary figures: never lose the reference point over them
+        out["secondary_error"] = repr(e)
     del eng, base
     torch.cuda.empty_cache()
     return out
 
 
+def scaling_reference(args, device, ggnn, steps):
+    return one_gpu_reference(args, device, ggnn, steps)
+
+
 def run_single(args, device, ggnn):
-    base = synthetic(args.dataset, args.n_base, args.dim, 1234, device)
-    query = synthetic(args.dataset, args.n_query, args.dim, 4321, device)
+    measure = _measure(args)
+    if args.n_base > 5_000_000:
+        base = torch.empty((args.n_base, args.dim), device=device,
+                           dtype=torch.uint8 if args.dtype == "u8" else torch.float32)
+        for lo in range(0, args.n_base, 5_000_000):
+            hi = min(args.n_base, lo + 5_000_000)
+            base[lo:hi] = make_data(args, args.dataset, hi - lo, 1234 + lo, device)
+    else:
+        base = make_data(args, args.dataset, args.n_base, 1234, device)
+    query = make_data(args, args.dataset, args.n_query, 4321, device)
     eng = ggnn.GGNN()
-    eng.set_base(base)
+    eng.set_base_reference(base)
     eng.set_return_results_on_gpu(True)
     t0 = time.perf_counter()
-    eng.build(args.k_build, args.tau_build, args.refine)
+    eng.build(args.k_build, args.tau_build, args.refine, measure)
     torch.cuda.synchronize()
     build_wall_s = time.perf_counter() - t0
     build_kernel_s = eng.last_timing_ms()["build_ms"] / 1000.0
 
     def step():
-        return eng.query(query, args.k, args.tau_query, args.max_iters)
+        return eng.query(query, args.k, args.tau_query, args.max_iters, measure)
 
     # ground truth by exact brute force on the same data (untimed)
-    gt, _ = eng.bf_query(query, args.k)
+    gt, _ = eng.bf_query(query, args.k, measure)
     bf_ms = eng.last_timing_ms()["bf_query_ms"]
     bf_rescanned = eng.last_bf_query_rescanned()
 
@@ -332,15 +506,15 @@ def run_single(args, device, ggnn):
 
     # the operating point was chosen on the query set above (seed 4321); a query set it has never
     # seen tells whether the recall figure generalises
-    held = synthetic(args.dataset, args.n_query, args.dim, 8642, device)
-    held_gt, _ = eng.bf_query(held, args.k)
-    held_ids, _ = eng.query(held, args.k, args.tau_query, args.max_iters)
+    held = make_data(args, args.dataset, args.n_query, 8642, device)
+    held_gt, _ = eng.bf_query(held, args.k, measure)
+    held_ids, _ = eng.query(held, args.k, args.tau_query, args.max_iters, measure)
     recall_heldout = recall_at_k(held_ids, held_gt)
     del held, held_gt, held_ids
 
     # work counters of one pass (untimed extra run) for the roofline figure
     eng.set_collect_counters(True)
-    eng.query(query, args.k, args.tau_query, args.max_iters)
+    eng.query(query, args.k, args.tau_query, args.max_iters, measure)
     cnt = eng.last_query_counters()
     rows = eng.last_query_rows_read()
     eng.set_collect_counters(False)
@@ -365,12 +539,12 @@ def run_single(args, device, ggnn):
     # occupancy); not part of `value`
     saturated = None
     if args.saturated_batch:
-        big = synthetic(args.dataset, 10 * args.n_query, args.dim, 9876, device)
+        big = make_data(args, args.dataset, 10 * args.n_query, 9876, device)
         for _ in range(2):
-            eng.query(big, args.k, args.tau_query, args.max_iters)
+            eng.query(big, args.k, args.tau_query, args.max_iters, measure)
         sat_ms = []
         for _ in range(3):
-            eng.query(big, args.k, args.tau_query, args.max_iters)
+            eng.query(big, args.k, args.tau_query, args.max_iters, measure)
             sat_ms.append(eng.last_timing_ms()["query_ms"])
         saturated = {"n_query": int(big.shape[0]), "query_kernel_ms": float(np.mean(sat_ms)),
                      "queries_per_s": big.shape[0] / (float(np.mean(sat_ms)) * 1e-3)}
@@ -382,11 +556,11 @@ def run_single(args, device, ggnn):
     pipelined = None
     if not args.no_pipelined:
         for slot in range(2):
-            eng.query_async(query, args.k, args.tau_query, args.max_iters, slot=slot)
+            eng.query_async(query, args.k, args.tau_query, args.max_iters, measure, slot=slot)
         eng.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        outs = [eng.query_async(query, args.k, args.tau_query, args.max_iters, slot=i % 2)
+        outs = [eng.query_async(query, args.k, args.tau_query, args.max_iters, measure, slot=i % 2)
                 for i in range(args.steps)]
         eng.synchronize()
         pip_s = (time.perf_counter() - t0) / args.steps
@@ -398,61 +572,75 @@ def run_single(args, device, ggnn):
         del outs
 
     nq, d, k = args.n_query, args.dim, args.k
+    esz = 1 if args.dtype == "u8" else 4
     ms_per_step = elapsed / args.steps * 1000.0
     value = nq / (elapsed / args.steps)
     # bytes_q = D*s + n_dist*D*s + n_pop*KBuild*4 + S*4 + 8 + K*8 is what the
     # reference's algorithm moves.  With the exact pre-screen a distance evaluation
     # reads a D-byte code row and only the candidates that pass it read their 4D-byte float row:
     # the algorithmic bytes of THIS kernel are counted from its own row counters.
-    fixed = nq * d * 4 + cnt["n_pop"] * args.k_build * 4 + nq * (32 * 4 + 8 + k * 8)
-    ref_bytes = fixed + cnt["n_dist"] * d * 4
+    fixed = nq * d * esz + cnt["n_pop"] * args.k_build * 4 + nq * (32 * 4 + 8 + k * 8)
+    ref_bytes = fixed + cnt["n_dist"] * d * esz
     code_dim = (d + 15) // 16 * 16
     prescreened = rows["code_rows"] > 0
-    alg_bytes = fixed + rows["float_rows"] * d * 4 + rows["code_rows"] * code_dim
+    alg_bytes = fixed + rows["float_rows"] * d * esz + rows["code_rows"] * code_dim
     if prescreened:
         alg_bytes += nq * (code_dim + 8) * 4  # per-dimension offsets + header, per query
     avg_kernel_ms = float(np.mean(kernel_ms))
     t_kernel = avg_kernel_ms * 1e-3
     alg_gbs = alg_bytes / t_kernel / 1e9
     traffic = pmc_traffic(args, prescreened)
-    sq, sq_file = pmc_sq(args, prescreened)
-    kernel_name = ("query_kernel<float,16,2,1,L2,Prescreen<8,1>,HB=1>" if prescreened
-                   else "query_kernel<float,16,2,1,L2,NoPrescreen>")
-    hbm_block = {
-        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "own_algorithmic": {"bytes_per_launch": alg_bytes, "achieved": alg_gbs,
-                            "frac": alg_gbs / HBM_PEAK_GBS},
-        "measured_fabric_traffic": (None if traffic is None else {
-            "bytes_per_launch": traffic, "achieved": traffic / t_kernel / 1e9,
-            "frac": traffic / t_kernel / 1e9 / HBM_PEAK_GBS,
-            "note": "FETCH_SIZE x2 + WRITE_SIZE of the committed PMC passes; Infinity-Cache "
-                    "hits are included (see profiles/*_pmc_l2.json for the L2 hit rate)"}),
-        "reference_algorithm_equivalent": {
-            "bytes_per_launch": ref_bytes, "achieved": ref_bytes / t_kernel / 1e9,
-            "frac": ref_bytes / t_kernel / 1e9 / HBM_PEAK_GBS,
-            "note": "bytes AVOIDED, not moved: SURVEY 8(d)'s n_dist x 4D formula over this "
-                    "kernel's time; > 1 is possible because the exact pre-screen reads D-byte "
-                    "code rows for most evaluations"},
-    }
-    if sq and "SQ_ACTIVE_INST_VALU" in sq:
-        peak = N_SIMD * CLOCK_HZ / 4.0
-        achieved = sq["SQ_ACTIVE_INST_VALU"] / t_kernel
-        roofline = {"bound": "valu", "achieved": achieved / 1e9, "peak": peak / 1e9,
-                    "unit": "G VALU-busy SIMD quad-cycles/s", "frac": achieved / peak,
-                    "traffic": traffic, "kernel": kernel_name, "counters_from": sq_file,
-                    "valu_insts_per_pop": sq.get("SQ_INSTS_VALU", 0.0) / max(1, cnt["n_pop"]),
-                    "note": "the kernel is VALU-issue bound: SQ_ACTIVE_INST_VALU per launch "
-                            "(committed PMC pass of this same workload) / (live HIP-event kernel "
-                            "time x 1024 SIMDs x 2.4 GHz / 4); byte rates in `hbm`",
-                    "hbm": hbm_block}
+    sq, sq_file, sq_note = pmc_sq(args, prescreened)
+    default_shape = (args.dtype, args.measure, args.dim) == ("f32", "l2", 128)
+    if default_shape and args.max_iters <= 512 and args.k <= 15:
+        kernel_name = ("query_kernel<float,16,2,1,L2,Prescreen<8,1>,HB=1>" if prescreened
+                       else "query_kernel<float,16,2,1,L2,NoPrescreen>")
     else:
-        roofline = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
-                    "note": "no committed SQ counters for this workload: byte rate of the "
-                            "kernel's own algorithmic bytes (the default workload reports the "
-                            "VALU-issue fraction that actually binds)", "hbm": hbm_block}
+        kernel_name = (f"query_kernel<{args.dtype}, D={d}, {args.measure}, "
+                       f"{'Prescreen' if prescreened else 'NoPrescreen'}> (variant chosen by the engine)")
+    clock = engine_clock_hz(device)
+    valu = None
+    if sq and "SQ_ACTIVE_INST_VALU" in sq:
+        peak = N_SIMD * clock / 4.0
+        valu = {"achieved": sq["SQ_ACTIVE_INST_VALU"] / t_kernel / 1e9, "peak": peak / 1e9,
+                "unit": "G VALU-busy SIMD quad-cycles/s",
+                "frac": sq["SQ_ACTIVE_INST_VALU"] / t_kernel / peak,
+                "engine_clock_hz": clock, "counters_from": sq_file, "kernel_in_profile": sq["_kernel"],
+                "valu_insts_per_pop": sq.get("SQ_INSTS_VALU", 0.0) / max(1, cnt["n_pop"]),
+                "note": "SQ_ACTIVE_INST_VALU per launch (committed PMC pass of this workload, "
+                        "collected with the same kernel sources) / (live kernel time x 1024 SIMDs "
+                        "x reported engine clock / 4): the instruction-issue share of the kernel "
+                        "time -- what actually limits the pre-screened kernel"}
+    roofline = {
+        "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
+        "bytes_per_launch": alg_bytes, "kernel_ms": avg_kernel_ms,
+        "definition": "algorithmic bytes of this kernel per launch (rows it reads: "
+                      "float_rows x D x s + code_rows x Dc, graph rows n_pop x KBuild x 4, query, "
+                      "start ids, results; live work counters of this run) / average launch "
+                      "duration (HIP events on the engine's stream, this run) / 8 TB/s",
+        "traffic_note": ("FETCH_SIZE x2 (gfx950 16 B/lane correction) + WRITE_SIZE per launch from "
+                         "the committed PMC passes of this workload" if traffic is not None else
+                         "null: no committed FETCH_SIZE/WRITE_SIZE pass matches this workload and "
+                         "these kernel sources"),
+        "secondary": {
+            "reference_algorithm_bytes": {
+                "bytes_per_launch": ref_bytes, "achieved": ref_bytes / t_kernel / 1e9,
+                "frac": ref_bytes / t_kernel / 1e9 / HBM_PEAK_GBS,
+                "note": "SURVEY 8(d)'s formula with n_dist x D x s: what the reference's algorithm "
+                        "would move for the same answers.  With the exact pre-screen most "
+                        "evaluations read a D-byte code row instead, so this is bytes AVOIDED "
+                        "and may exceed the peak"},
+            "measured_fabric_traffic": (None if traffic is None else {
+                "bytes_per_launch": traffic, "achieved": traffic / t_kernel / 1e9,
+                "frac": traffic / t_kernel / 1e9 / HBM_PEAK_GBS,
+                "over_algorithmic": traffic / alg_bytes}),
+            "valu_issue": valu if valu is not None else {"frac": None, "note": sq_note},
+        },
+    }
     roofline["without_prescreen"] = (None if plain_ms is None else {
-        "kernel": "query_kernel<float,16,2,1,L2,NoPrescreen>", "query_kernel_ms": plain_ms,
+        "kernel": "query_kernel<float,16,2,1,L2,NoPrescreen>" if default_shape else "NoPrescreen variant",
+        "query_kernel_ms": plain_ms,
         "queries_per_s": nq / (plain_ms * 1e-3), "bound": "hbm + infinity cache",
         "achieved": ref_bytes / (plain_ms * 1e-3) / 1e9,
         "frac": ref_bytes / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -463,16 +651,12 @@ def run_single(args, device, ggnn):
         "metric": "queries/sec @ recall@10 (SIFT1M-shaped, k=10)",
         "value": value, "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload_string(args), "parallelism": "single GPU"},
         "recall_at_10": recall, "recall_at_10_heldout_queries": recall_heldout, "c_at_1": c1,
         "graph_build_s": build_kernel_s, "graph_build_wall_s": build_wall_s,
         "bf_query_ms": bf_ms,
-        "bf_query": {"ms": bf_ms,
-                     "kernel": "bf_mfma_kernel (v_mfma_f32_32x32x2_f32) + certified exact re-rank",
-                     "tflops": 2.0 * nq * args.n_base * d / (bf_ms * 1e-3) / 1e12,
-                     "mfma_frac_of_f32_peak": 2.0 * nq * args.n_base * d / (bf_ms * 1e-3) / F32_MFMA_PEAK,
-                     "queries_rescanned_by_the_exact_scan": bf_rescanned},
+        "bf_query": bf_block(args, bf_ms, bf_rescanned),
         "query_kernel_ms": avg_kernel_ms,
         "n_dist_per_query": cnt["n_dist"] / nq, "n_pop_per_query": cnt["n_pop"] / nq,
         "saturated_batch": saturated,
@@ -481,30 +665,34 @@ def run_single(args, device, ggnn):
         "code_rows_per_query": rows["code_rows"] / nq,
         "roofline": roofline,
     }
-    if not args.no_build_roofline:
+    plain_f32_l2 = (args.dtype, args.measure) == ("f32", "l2")
+    if not args.no_build_roofline and plain_f32_l2:
         out["build"] = {"graph_build_s": build_kernel_s, "merge_kernel": build_roofline(args, eng, base)}
     if not args.no_datasets:
-        ds = dataset_sweep(args, device, ggnn)
-        ds[args.dataset] = {"query_kernel_ms": avg_kernel_ms, "queries_per_s": nq / t_kernel,
-                            "recall_at_10": recall, "graph_build_s": build_kernel_s}
-        out["datasets"] = {"operating_point": f"tau_query={args.tau_query}, "
-                                              f"max_iterations={args.max_iters}, k={args.k}",
-                           "note": "same engine settings on other synthetic bases (latent "
-                                   "dimension 24 / 32, i.i.d.): harder bases need more effort; "
-                                   "the second point of each is tau 1.0 / 400 iterations",
-                           "results": ds}
-    if not args.no_datasets:
+        out["recall_targets"] = {
+            "target": "recall@10 >= 0.99 against each base's own exact bf_query",
+            "grid": {"tau_query": list(SEARCH_TAUS), "max_iterations": list(SEARCH_ITERS)},
+            "note": "queries/s AT the recall target per synthetic base: the cheapest point of "
+                    "the grid that reaches it (query-kernel time, 10k-query blocking launches); "
+                    "`same_settings_as_headline` is the headline's own (tau, iterations) on that "
+                    "base.  The headline dataset is the easiest of these.",
+            "results": recall_target_sweep(args, device, ggnn, eng, query, gt)}
         # the reference's own four SIFT1M settings (sift1m_fvecs.py:19-30 / ggnn_benchmark.cpp:
-        # 196-200: tau 0.34 / 0.41 / 0.51 at 200 iterations, 0.64 at 400) and two higher-effort
-        # points on this synthetic base: recall against the exact ground truth, kernel rate
+        # 196-200: tau 0.34 / 0.41 / 0.51 at 200 iterations, 0.64 at 400) on this synthetic base
         pts = {}
-        for tau, iters in ((0.34, 200), (0.41, 200), (0.51, 200), (0.64, 400), (0.9, 175), (1.0, 400)):
+        for tau, iters in ((0.34, 200), (0.41, 200), (0.51, 200), (0.64, 400), (1.0, 400)):
             r = measure_point(eng, query, gt, args, 5, tau, iters)
-            ids_p, _ = eng.query(query, args.k, tau, iters)
+            ids_p, _ = eng.query(query, args.k, tau, iters, measure)
             r["c_at_1"] = (ids_p[:, 0] == gt[:, 0]).float().mean().item()
             pts[f"tau={tau},iters={iters}"] = r
         out["operating_points"] = pts
-    if not args.no_scaling_reference:
+    sift_dir = os.environ.get("GGNN_SIFT1M_DIR")
+    if sift_dir and not args.lean:
+        try:
+            out["sift1m_real_files"] = sift1m_real(sift_dir, ggnn, device)
+        except Exception as e:   # informational: never lose the line over it
+            out["sift1m_real_files"] = {"error": repr(e)}
+    if not args.no_scaling_reference and plain_f32_l2:
         out["strong_scaling_one_gpu"] = scaling_reference(args, device, ggnn, max(5, args.steps // 2))
     if not args.no_cpu_baseline:
         graph = eng.get_graph(0)
@@ -519,22 +707,27 @@ def run_single(args, device, ggnn):
     print(json.dumps(out), flush=True)
 
 
-def run_sharded(args, device, ggnn, world, rank):
-    """strong scaling on a fixed base: TOTAL_SHARDS shards spread over the ranks"""
+def sharded_case(args, device, world, rank, spg):
+    """One base of TOTAL_SHARDS x args.n_base points partitioned over the ranks (one process per
+    GPU): blocking 10k-query steps (the contract's timed region), a saturating 100k-query batch
+    and two batches in flight.  Times are the MAX over ranks."""
     from ggnn_amd.distributed import ShardedGGNN
-    if TOTAL_SHARDS % world:
-        raise SystemExit(f"--gpus must divide {TOTAL_SHARDS}")
-    spg = TOTAL_SHARDS // world
+    red_dev = device if args.backend == "nccl" else "cpu"
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
 
-    base = torch.cat([synthetic(args.dataset, args.n_base, args.dim, 1234 + rank * spg + s, device)
-                      for s in range(spg)])
+    def max_over_ranks(*vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    base = big_base(args, spg * args.n_base, rank * spg, device)
     query = synthetic(args.dataset, args.n_query, args.dim, 4321, device)
     sharded = ShardedGGNN()
-    sharded.set_base(base, is_local_slice=True)
+    sharded.engine.set_base_reference(base)
+    sharded.n_local = int(base.shape[0])
     sharded.set_shard_size(args.n_base)
     eng = sharded.engine
     t0 = time.perf_counter()
@@ -543,8 +736,8 @@ def run_sharded(args, device, ggnn, world, rank):
     build_wall_s = time.perf_counter() - t0
     build_kernel_s = eng.last_timing_ms()["build_ms"] / 1000.0
 
-    def step():
-        return sharded.query(query, args.k, args.tau_query, args.max_iters)
+    def step(q=query):
+        return sharded.query(q, args.k, args.tau_query, args.max_iters)
 
     gt, _ = sharded.bf_query(query, args.k)
     for _ in range(args.warmup):
@@ -556,21 +749,40 @@ def run_sharded(args, device, ggnn, world, rank):
         ids, dists = step()
         kernel_ms.append(eng.last_timing_ms()["query_ms"])
     barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64,
-                     device=device if args.backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    recall = recall_at_k(ids, gt)
+    elapsed, = max_over_ranks(time.perf_counter() - t0)
+    out = {"n_base_per_shard": args.n_base, "shards_per_gpu": spg,
+           "elapsed_s": elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+           "queries_per_s": args.n_query / (elapsed / args.steps),
+           "recall_at_10": recall_at_k(ids, gt),
+           "graph_build_s_per_gpu": build_kernel_s, "graph_build_wall_s": build_wall_s,
+           "query_kernel_ms_sum_over_local_shards": float(np.mean(kernel_ms))}
 
-    # informational: two batches in flight per rank (local search of batch i+1 enqueued before
-    # batch i is exchanged and merged); not part of `value`
-    pipelined = None
+    # informational, never part of `value`; every rank takes part in every reduction whether or
+    # not its own attempt worked
+    sat, err = -1.0, 0.0
+    nbig = 10 * args.n_query
+    try:
+        big = synthetic(args.dataset, nbig, args.dim, 9876, device)
+        step(big)
+        barrier()
+        reps = max(2, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(big)
+        barrier()
+        sat = (time.perf_counter() - t0) / reps
+        del big
+    except Exception as e:
+        err, out["saturated_batch_error"] = 1.0, repr(e)
+    sat, err = max_over_ranks(sat, err)
+    if not err and sat > 0:
+        out["saturated_batch"] = {"n_query": nbig, "ms_per_step": sat * 1e3,
+                                  "queries_per_s": nbig / sat}
     if not args.no_pipelined:
-        pip, same, err = -1.0, False, None
-        try:  # informational only: never lose the main line over it
+        pip, same, err = -1.0, False, 0.0
+        try:
             sharded.finish(sharded.query_async(query, args.k, args.tau_query, args.max_iters, slot=0))
-            torch.cuda.synchronize()
+            barrier()
             t0 = time.perf_counter()
             tickets, last = [], None
             for i in range(args.steps):
@@ -584,65 +796,193 @@ def run_sharded(args, device, ggnn, world, rank):
             pip = (time.perf_counter() - t0) / args.steps
             same = bool(torch.equal(last[0], ids) and torch.equal(last[1], dists))
         except Exception as e:
-            err = repr(e)
-        # every rank takes part in this reduction whether or not its attempt worked
-        tp = torch.tensor([pip, 0.0 if err else 1.0], dtype=torch.float64,
-                          device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        worst = float(tp[0].item())
-        if err is None and worst > 0:
-            pipelined = {"batches_in_flight": 2, "ms_per_batch": worst * 1e3,
-                         "queries_per_s": args.n_query / worst, "results_equal_blocking": same}
-        else:
-            pipelined = {"error": err or "failed on another rank"}
+            err, out["pipelined_error"] = 1.0, repr(e)
+        pip, err = max_over_ranks(pip, err)
+        if not err and pip > 0:
+            out["pipelined_batches"] = {"batches_in_flight": 2, "ms_per_batch": pip * 1e3,
+                                        "queries_per_s": args.n_query / pip,
+                                        "results_equal_blocking": same}
     del sharded, eng, base
     torch.cuda.empty_cache()
-
-    # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
-    one = None
-    if rank == 0 and not args.no_scaling_reference:
-        try:
-            one = scaling_reference(args, device, ggnn, max(5, args.steps // 2))
-        except Exception as e:  # e.g. not enough free memory next to another job: keep the line
-            one = {"error": repr(e)}
     barrier()
+    return out
+
+
+def speedups(case, one):
+    """speed-up of every measured mode over the same mode of the one-GPU point of the same base"""
+    if not one or "queries_per_s" not in one:
+        return None
+    r = {"blocking": case["queries_per_s"] / one["queries_per_s"]}
+    for mode in ("saturated_batch", "pipelined_batches"):
+        if mode in case and mode in one:
+            r[mode] = case[mode]["queries_per_s"] / one[mode]["queries_per_s"]
+    return r
+
+
+def run_in_process(args, ggnn):
+    """The reference's own multi-GPU form (examples/cpp-and-cuda/ggnn_main_multi_gpu.cpp:
+    ONE handle, set_gpus([...]) + set_shard_size): host thread per GPU, in-engine RCCL
+    all-gather of the packed candidates over xGMI, per-GPU slice merges.  Prints one JSON line."""
+    gpus = [0] * args.gpus if args.single_device else list(range(args.gpus))
+    device = torch.device("cuda", gpus[0])
+    torch.cuda.set_device(device)
+    base = big_base(args, TOTAL_SHARDS * args.n_base, 0, device)
+    query = synthetic(args.dataset, args.n_query, args.dim, 4321, device)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_gpus(gpus)
+    eng.set_shard_size(args.n_base)
+    t0 = time.perf_counter()
+    eng.build(args.k_build, args.tau_build, args.refine)
+    build_wall_s = time.perf_counter() - t0
+
+    def step(q=query):
+        return eng.query(q, args.k, args.tau_query, args.max_iters)
+
+    for _ in range(max(2, args.warmup)):
+        ids, dists = step()
+    el, (ids, dists) = timed(step, args.steps, torch.cuda.synchronize)
+    out = {"form": "one handle, set_gpus(%s), shard size %d" % (gpus, args.n_base),
+           "exchange": eng.last_exchange(), "queries_per_s": args.n_query / el,
+           "ms_per_step": el * 1e3, "graph_build_wall_s": build_wall_s,
+           "query_kernel_ms_max_over_gpus": eng.last_timing_ms()["query_ms"],
+           "results": "merged [Nq, K] on the host (as the reference returns them)"}
+    try:
+        big = synthetic(args.dataset, 10 * args.n_query, args.dim, 9876, device)
+        step(big)
+        el_b, _ = timed(lambda: step(big), max(2, args.steps // 4), torch.cuda.synchronize)
+        out["saturated_batch"] = {"n_query": int(big.shape[0]), "ms_per_step": el_b * 1e3,
+                                  "queries_per_s": big.shape[0] / el_b}
+        del big
+        eng.query_async(query, args.k, args.tau_query, args.max_iters, slot=0)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        tickets = [eng.query_async(query, args.k, args.tau_query, args.max_iters, slot=i % 2)
+                   for i in range(args.steps)]
+        eng.synchronize()
+        el_p = (time.perf_counter() - t0) / args.steps
+        same = all(torch.equal(t.ids.cpu(), ids) and torch.equal(t.dists.cpu(), dists)
+                   for t in tickets)
+        out["pipelined_batches"] = {"batches_in_flight": 2, "ms_per_batch": el_p * 1e3,
+                                    "queries_per_s": args.n_query / el_p,
+                                    "results_equal_blocking": bool(same)}
+    except Exception as e:
+        out["secondary_error"] = repr(e)
+    print(json.dumps(out), flush=True)
+
+
+def in_process_child(args, n_base, timeout_s):
+    """rank 0 runs the one-handle form in a child process of its own (a crash or a hang there
+    must not cost the benchmark line); the other ranks idle at a barrier meanwhile"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                        "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE",
+                        "TORCHELASTIC_RUN_ID", "GGNN_EXCHANGE")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process", "--gpus", str(args.gpus),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--n-base", str(n_base),
+           "--n-query", str(args.n_query), "--dim", str(args.dim), "--k", str(args.k),
+           "--k-build", str(args.k_build), "--tau-build", str(args.tau_build),
+           "--refine", str(args.refine), "--tau-query", str(args.tau_query),
+           "--max-iters", str(args.max_iters), "--dataset", args.dataset]
+    if args.single_device:
+        cmd.append("--single-device")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s} s"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def run_sharded(args, device, ggnn, world, rank):
+    """strong scaling on a fixed base of TOTAL_SHARDS shards spread over the ranks"""
+    if TOTAL_SHARDS % world:
+        raise SystemExit(f"--gpus must divide {TOTAL_SHARDS}")
+    spg = TOTAL_SHARDS // world
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    ref_steps = max(5, args.steps // 2)
+    main_base = args.n_base
+    cases = []
+    for n_base in [main_base] + ([args.secondary_n_base] if args.secondary_n_base and
+                                 args.secondary_n_base != main_base else []):
+        args.n_base = n_base
+        case = sharded_case(args, device, world, rank, spg)
+        # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
+        one = None
+        if rank == 0 and not args.no_scaling_reference:
+            try:
+                one = one_gpu_reference(args, device, ggnn, ref_steps)
+            except Exception as e:  # e.g. not enough free memory next to another job: keep the line
+                one = {"error": repr(e)}
+        barrier()
+        # ... and the one-handle form (in-engine RCCL) in a child process of rank 0
+        inproc = None
+        if not args.no_in_process and n_base == main_base:
+            if rank == 0:
+                inproc = in_process_child(args, n_base, args.in_process_timeout)
+            barrier()
+        case["one_gpu_same_base"] = one
+        case["speedup_vs_one_gpu_same_base"] = speedups(case, one)
+        if inproc is not None:
+            case["in_process_handle"] = inproc
+            if "queries_per_s" in inproc:
+                inproc["speedup_vs_one_gpu_same_base"] = speedups(inproc, one)
+        cases.append(case)
+    args.n_base = main_base
 
     if rank == 0:
-        nq = args.n_query
-        value = nq / (elapsed / args.steps)
+        main, nq = cases[0], args.n_query
+        total = TOTAL_SHARDS * main_base
+        sp = main["speedup_vs_one_gpu_same_base"] or {}
         out = {
             "metric": "queries/sec @ recall@10 (SIFT1M-shaped shards, k=10)",
-            "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1000.0,
+            "value": main["queries_per_s"], "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"fixed base of {TOTAL_SHARDS} shards x {args.n_base} points "
-                                   f"({TOTAL_SHARDS * args.n_base} x {args.dim} f32, "
-                                   f"{args.dataset}), {nq} queries, k={args.k}, "
-                                   f"k_build={args.k_build}, tau_build={args.tau_build}, "
-                                   f"refine={args.refine}, tau_query={args.tau_query}, "
-                                   f"max_iterations={args.max_iters}",
+            "config": {"workload": f"fixed base of {total} points = {TOTAL_SHARDS} shards x "
+                                   f"{main_base} ({total} x {args.dim} f32, {args.dataset}), "
+                                   f"{nq} queries, k={args.k}, k_build={args.k_build}, "
+                                   f"tau_build={args.tau_build}, refine={args.refine}, "
+                                   f"tau_query={args.tau_query}, max_iterations={args.max_iters}",
                        "parallelism": f"base partitioned over {world} ranks ({spg} resident "
                                       f"shard(s) per GPU), every rank searches all queries in its "
-                                      f"shards, one RCCL all-gather of the sorted candidates + "
-                                      f"device k-way merge; value = Nq / T"},
-            "recall_at_10": recall,
-            "graph_build_s_per_gpu": build_kernel_s, "graph_build_wall_s": build_wall_s,
-            "query_kernel_ms_sum_over_local_shards": float(np.mean(kernel_ms)),
-            "one_gpu_same_base": one,
-            "speedup_vs_one_gpu_same_base": (None if not one or "queries_per_s" not in one
-                                             else value / one["queries_per_s"]),
-            "pipelined_batches": pipelined,
-            "pipelined_speedup_vs_one_gpu_same_base": (
-                None if not one or "queries_per_s" not in one or not pipelined
-                or "queries_per_s" not in pipelined
-                else pipelined["queries_per_s"] / one["queries_per_s"]),
+                                      f"shards, ONE packed RCCL all-gather of the sorted candidates "
+                                      f"+ device k-way merge; value = Nq / T of blocking steps"},
+            "recall_at_10": main["recall_at_10"],
+            "graph_build_s_per_gpu": main["graph_build_s_per_gpu"],
+            "graph_build_wall_s": main["graph_build_wall_s"],
+            "query_kernel_ms_sum_over_local_shards": main["query_kernel_ms_sum_over_local_shards"],
+            "one_gpu_same_base": main["one_gpu_same_base"],
+            "speedup_vs_one_gpu_same_base": sp.get("blocking"),
+            "saturated_batch": main.get("saturated_batch"),
+            "saturated_speedup_vs_one_gpu_same_base": sp.get("saturated_batch"),
+            "pipelined_batches": main.get("pipelined_batches"),
+            "pipelined_speedup_vs_one_gpu_same_base": sp.get("pipelined_batches"),
+            "in_process_handle": main.get("in_process_handle"),
+            "secondary_base": (None if len(cases) < 2 else dict(
+                cases[1], note=f"the same series on {TOTAL_SHARDS} x {cases[1]['n_base_per_shard']} "
+                               "points (the round-1/2 default)")),
             "roofline": None, "cpu_baseline": None,
-            "note": "N=1 of this command is the BASELINE single-shard configuration; the "
-                    "multi-GPU series keeps the BASE fixed (8 shards) instead, so compare with "
-                    "one_gpu_same_base (also in the N=1 line as strong_scaling_one_gpu), not "
-                    "with the N=1 `value`",
+            "note": "N=1 of this command is the BASELINE single-shard configuration (1M points); "
+                    "the multi-GPU series keeps the BASE fixed (north star: 100M points) instead, "
+                    "so compare with one_gpu_same_base -- all 8 shards resident on one MI355X, "
+                    "measured by rank 0 in this same run -- not with the N=1 `value`; the three "
+                    "speed-ups compare like with like (blocking / 100k-query batch / two batches "
+                    "in flight)",
         }
+        for k_ in ("saturated_batch_error", "pipelined_error"):
+            if k_ in main:
+                out[k_] = main[k_]
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 
@@ -652,7 +992,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-base", type=int, default=1_000_000, help="points per shard")
+    ap.add_argument("--n-base", type=int, default=None,
+                    help="points per shard (default: 1M at N=1 = BASELINE configs[1]; 12.5M at "
+                         "N>1 = the north star's 100M-point base in 8 shards)")
+    ap.add_argument("--secondary-n-base", type=int, default=1_000_000,
+                    help="N>1: a second, smaller fixed base of 8 such shards (0: skip)")
+    ap.add_argument("--no-in-process", action="store_true",
+                    help="N>1: skip the one-handle set_gpus([...]) form (in-engine RCCL)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="run ONLY the one-handle form over --gpus GPUs in this process")
+    ap.add_argument("--in-process-timeout", type=float, default=420.0)
     ap.add_argument("--n-query", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=10)
@@ -662,6 +1011,9 @@ def main():
     ap.add_argument("--tau-query", type=float, default=0.9)
     ap.add_argument("--max-iters", type=int, default=175)
     ap.add_argument("--dataset", default="lowrank16")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "u8"),
+                    help="element type of base and queries (u8: BASELINE configs[4] rows)")
+    ap.add_argument("--measure", default="l2", choices=("l2", "cosine"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-datasets", action="store_true", help="skip the other synthetic bases")
     ap.add_argument("--no-build-roofline", action="store_true")
@@ -686,6 +1038,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.n_base is None:
+        args.n_base = 12_500_000 if (world > 1 or args.in_process) else 1_000_000
+    if args.in_process:
+        import ggnn_amd as ggnn
+        ggnn.set_log_level(-1)
+        run_in_process(args, ggnn)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")

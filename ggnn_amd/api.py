@@ -160,6 +160,27 @@ class Graph:
 # ---------------------------------------------------------------------------------------------
 # GGNN (nanobind.cu:184-268 over ggnn.cuh:42-182)
 # ---------------------------------------------------------------------------------------------
+_ASYNC_SLOTS = 4   # DeviceCtx::kShardStreams: slots that map to the same engine stream
+
+
+class QueryTicket:
+    """Result of `GGNN.query_async`: `ids, dists = ticket` works as before; `query` keeps the
+    input alive; `done` is set by `synchronize()`."""
+    __slots__ = ("query", "ids", "dists", "slot", "done")
+
+    def __init__(self, query, ids, dists, slot):
+        self.query, self.ids, self.dists, self.slot, self.done = query, ids, dists, slot, False
+
+    def __iter__(self):
+        return iter((self.ids, self.dists))
+
+    def __getitem__(self, i):
+        return (self.ids, self.dists)[i]
+
+    def __len__(self):
+        return 2
+
+
 class GGNN:
     """GGNN main class. Provides functionality for building, loading, storing, and querying
     nearest neighbor graphs on the GPU."""
@@ -172,6 +193,8 @@ class GGNN:
         self._keepalive = None
         self._return_results_on_gpu = False
         self._shards = 1
+        self._inflight = {}   # slot -> QueryTickets whose kernels may still be running
+        self._num_gpus = 1
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -211,6 +234,7 @@ class GGNN:
         ids = [int(g) for g in gpu_ids]
         arr = (C.c_int * len(ids))(*ids)
         self._check(lib().ggnn_set_gpus(self._h, arr, len(ids)))
+        self._num_gpus = max(1, len(ids))
 
     def set_shard_size(self, n_shard):
         self._check(lib().ggnn_set_shard_size(self._h, int(n_shard)))
@@ -277,26 +301,54 @@ class GGNN:
 
     def query_async(self, query, k_query, tau_query, max_iterations=400,
                     measure=DistanceMeasure.Euclidean, slot=0):
-        """Extension for serving: enqueue a batch and return GPU tensors that are valid after
-        `synchronize()`.  Batches with different `slot`s overlap on the device (one GPU, query on
-        that GPU); the result has the results-on-GPU shape [Nq, k_query * shards]."""
+        """Extension for serving: enqueue a batch and return a `QueryTicket` (unpacks like the
+        `(ids, dists)` pair) whose GPU tensors are valid after `synchronize()`.  Batches with
+        different `slot`s overlap on the device (one GPU, query on that GPU); the result has the
+        results-on-GPU shape [Nq, k_query * shards].
+
+        Lifetime: the kernels run on the engine's own streams, which torch's caching allocator
+        knows nothing about.  The engine object therefore keeps the query tensor and both
+        result tensors referenced until `synchronize()` (of that slot) has returned, whatever
+        the caller does with its own references -- a temporary passed as `query`, or a
+        rebound loop variable, cannot be recycled under a running kernel."""
         t = _as_tensor(query, what="query")
-        if not t.is_cuda:
-            raise RuntimeError("query_async needs the query on the GPU")
-        loc, dev = _loc(t)
-        ids, dists = self._out(t.shape[0], int(k_query) * self._shards, True, t.device)
+        if self._num_gpus > 1 or os.environ.get("GGNN_EXCHANGE") == "rccl":
+            # several GPUs (or the forced RCCL path of the tests): merged [Nq, k] results; host-side tensors are page-locked so that the
+            # engine's copies stay asynchronous
+            if not t.is_cuda and not t.is_pinned():
+                t = t.pin_memory()
+            dev = t.device.index if t.is_cuda else -1
+            if t.is_cuda:
+                ids, dists = self._out(t.shape[0], int(k_query), True, t.device)
+            else:
+                ids = torch.empty((t.shape[0], int(k_query)), dtype=torch.int32, pin_memory=True)
+                dists = torch.empty((t.shape[0], int(k_query)), dtype=torch.float32,
+                                    pin_memory=True)
+        else:
+            if not t.is_cuda:
+                raise RuntimeError("query_async needs the query on the GPU")
+            loc, dev = _loc(t)
+            ids, dists = self._out(t.shape[0], int(k_query) * self._shards, True, t.device)
         self._check(lib().ggnn_query_async(self._h, t.data_ptr(), t.shape[0], t.shape[1],
                                            _dtype_code(t), dev, int(k_query), float(tau_query),
                                            int(max_iterations), int(measure), ids.data_ptr(),
                                            dists.data_ptr(), int(slot)))
-        return ids, dists
+        ticket = QueryTicket(t, ids, dists, int(slot))
+        self._inflight.setdefault(int(slot) % _ASYNC_SLOTS, []).append(ticket)
+        return ticket
 
     def synchronize(self, slot=None):
-        """wait for every batch enqueued with query_async (or only for those of one slot)"""
+        """wait for every batch enqueued with query_async (or only for those of one slot); the
+        tensors of the finished batches are released to their owners"""
         if slot is None:
             self._check(lib().ggnn_synchronize(self._h))
+            done = [t for ts in self._inflight.values() for t in ts]
+            self._inflight.clear()
         else:
             self._check(lib().ggnn_synchronize_slot(self._h, int(slot)))
+            done = self._inflight.pop(int(slot) % _ASYNC_SLOTS, [])
+        for t in done:
+            t.done = True
 
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
         """Run a brute-force query and indices and distances."""

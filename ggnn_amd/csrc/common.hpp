@@ -222,12 +222,14 @@ void launch_merge_results_subset(uint32_t Nq, uint32_t k, uint32_t num_parts, ui
                                  hipStream_t stream);
 
 // ... and for the queries [first, first + count) only (every GPU of a multi-GPU handle merges its
-// own slice of the query set); outputs are indexed by the query number
+// own slice of the query set); outputs are indexed by the query number.  part_elems: distance
+// (in elements) between the rows of consecutive parts, 0 = Nq * stride (parts stored back to
+// back); the packed exchange keeps every part's ids and distances in one block of 2 * Nq * stride
 void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uint32_t stride,
                                 uint32_t id_offset_per_part, const int32_t* parts_ids,
                                 const float* parts_dists, int32_t* ids_out, float* dists_out,
                                 const uint32_t* qlist, const uint32_t* qcount, uint32_t first,
-                                uint32_t count, hipStream_t stream);
+                                uint32_t count, hipStream_t stream, size_t part_elems = 0);
 
 // host layout math (graph_config.cpp)
 void graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild, ggnn_graph_config* out);

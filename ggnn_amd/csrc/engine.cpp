@@ -72,6 +72,48 @@ struct DeviceBuffer {
   }
 };
 
+// page-locked host memory (slice copies of the multi-GPU exchange: a D2H copy into pageable
+// memory is staged and serialised by the runtime)
+struct PinnedBuffer {
+  void* p{nullptr};
+  size_t bytes{0};
+  PinnedBuffer() = default;
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  PinnedBuffer(PinnedBuffer&& o) noexcept : p(o.p), bytes(o.bytes)
+  {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  PinnedBuffer& operator=(PinnedBuffer&& o) noexcept
+  {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  ~PinnedBuffer() { release(); }
+  void grow(size_t n)
+  {
+    if (bytes >= n)
+      return;
+    release();
+    GGNN_HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault));
+    bytes = n;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
 // HIP-event stopwatch on one stream, on two events owned by the caller (DeviceCtx creates them
 // once: creating and destroying events costs ~10 us per query() otherwise)
 struct EventTimer {
@@ -211,10 +253,24 @@ struct DeviceCtx {
   hipEvent_t shard_done[kShardStreams] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_ready{nullptr};
   DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
-  // result staging of query(): grown on demand, kept between calls
-  DeviceBuffer r_ids, r_dists;  // this GPU's sorted rows [Nq, K * shards_per_gpu]
-  DeviceBuffer g_ids, g_dists;  // rows of all GPUs after the exchange [G][Nq, K * shards_per_gpu]
-  DeviceBuffer m_ids, m_dists;  // merged slice
+  // Result staging of query() / query_async(): grown on demand, kept between calls.  One set per
+  // lane: lanes [0, kShardStreams) belong to the asynchronous slots (their streams), lane
+  // kBlockingLane to the blocking query() on `stream`.  Ids and distance bit patterns share ONE
+  // buffer so that the exchange is one collective: r_pack = [ids: Nq x row][dists: Nq x row].
+  static constexpr int kBlockingLane = kShardStreams;
+  struct ExchangeBufs {
+    DeviceBuffer q_stage;  // the query set on this GPU when it has to be copied (async lanes)
+    DeviceBuffer r_pack;   // this GPU's sorted rows, ids then distances
+    DeviceBuffer g_pack;   // r_pack of all GPUs after the exchange, [G][2 * Nq * row]
+    DeviceBuffer m_pack;   // merged results, [ids: Nq x K][dists: Nq x K] (this GPU's slice filled)
+    PinnedBuffer h_pack;   // the merged slice on the host, [ids: count x K][dists: count x K]
+    hipEvent_t done{nullptr};  // local search of this lane finished (copy exchange)
+  };
+  ExchangeBufs xb[kShardStreams + 1];
+  hipStream_t lane_stream(int lane) const
+  {
+    return lane == kBlockingLane ? stream : shard_stream[lane];
+  }
   static void grow(DeviceBuffer& b, size_t bytes)
   {
     if (b.bytes < bytes)
@@ -242,12 +298,15 @@ struct DeviceCtx {
     o.ev_a = o.ev_b = o.ev_ready = nullptr;
     base_copy = std::move(o.base_copy);
     bf_rescanned = std::move(o.bf_rescanned);
-    r_ids = std::move(o.r_ids);
-    r_dists = std::move(o.r_dists);
-    g_ids = std::move(o.g_ids);
-    g_dists = std::move(o.g_dists);
-    m_ids = std::move(o.m_ids);
-    m_dists = std::move(o.m_dists);
+    for (int i = 0; i <= kShardStreams; ++i) {
+      xb[i].q_stage = std::move(o.xb[i].q_stage);
+      xb[i].r_pack = std::move(o.xb[i].r_pack);
+      xb[i].g_pack = std::move(o.xb[i].g_pack);
+      xb[i].m_pack = std::move(o.xb[i].m_pack);
+      xb[i].h_pack = std::move(o.xb[i].h_pack);
+      xb[i].done = o.xb[i].done;
+      o.xb[i].done = nullptr;
+    }
     d_base = o.d_base;
     first_shard = o.first_shard;
     shards = std::move(o.shards);
@@ -266,6 +325,9 @@ struct DeviceCtx {
           (void)hipEventDestroy(shard_done[i]);
           (void)hipStreamDestroy(shard_stream[i]);
         }
+      for (int i = 0; i <= kShardStreams; ++i)
+        if (xb[i].done)
+          (void)hipEventDestroy(xb[i].done);
       (void)hipStreamDestroy(stream);
     }
   }
@@ -944,15 +1006,15 @@ struct ggnn_handle {
     const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
     const size_t part = nq * row;
 
+    constexpr int lane = DeviceCtx::kBlockingLane;
     for_each_device([&](DeviceCtx& ctx) {
       Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
       int32_t* d_ids = ids_out;
       float* d_dists = dists_out;
       if (!direct) {
-        DeviceCtx::grow(ctx.r_ids, part * 4);
-        DeviceCtx::grow(ctx.r_dists, part * 4);
-        d_ids = ctx.r_ids.as<int32_t>();
-        d_dists = ctx.r_dists.as<float>();
+        DeviceCtx::grow(ctx.xb[lane].r_pack, 2 * part * 4);
+        d_ids = ctx.xb[lane].r_pack.as<int32_t>();
+        d_dists = reinterpret_cast<float*>(d_ids + part);
       }
       query_device(ctx, sq.ptr, nq, k_query, tau_query, max_iterations, measure, d_ids, d_dists);
     });
@@ -972,130 +1034,263 @@ struct ggnn_handle {
       // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
       DeviceCtx& d0 = devs[0];
       d0.activate();
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, d0.r_ids.p, row * 4, k_query * 4ull,
-                                      nq, hipMemcpyDeviceToHost, d0.stream));
-      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, d0.r_dists.p, row * 4,
+      const int32_t* r = d0.xb[lane].r_pack.as<int32_t>();
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(ids_out, k_query * 4ull, r, row * 4, k_query * 4ull, nq,
+                                      hipMemcpyDeviceToHost, d0.stream));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(dists_out, k_query * 4ull, r + part, row * 4,
                                       k_query * 4ull, nq, hipMemcpyDeviceToHost, d0.stream));
       GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
       last_exchange = "none";
       return;
     }
-    if (ensure_comms())
-      exchange_rccl(nq, k_query, row, ids_out, dists_out);
-    else
-      exchange_peer_copies(nq, k_query, row, ids_out, dists_out);
+    exchange(lane, nq, k_query, row, ids_out, dists_out, /*blocking=*/true);
   }
 
-  // Several GPUs, RCCL: every GPU contributes its sorted rows to ONE grouped all-gather (ids and
-  // distances of all ranks in one ncclGroup, over xGMI), merges a 1/G slice of the queries with
-  // id offset g * shards_per_gpu * N_shard (result_merger.cpp:115-116) and copies that slice to
-  // the caller's arrays.  The reference copies everything to the host and merges there with a
-  // heap per query (ggnn.cu:308-329, result_merger.cpp:51-149).
-  void exchange_rccl(uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out, float* dists_out)
+  // Combines the per-GPU rows of one lane into the caller's [Nq, K] arrays.  blocking: waits and
+  // copies through pinned staging; otherwise everything is only enqueued on the lane's streams
+  // (the caller's arrays are written by asynchronous copies: device or page-locked memory).
+  void exchange(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                float* dists_out, bool blocking)
+  {
+    if (ensure_comms()) {
+      try {
+        exchange_rccl(lane, nq, k_query, row, ids_out, dists_out, blocking);
+        return;
+      }
+      catch (const Error& e) {
+        // a failed collective leaves the communicators unusable: drop them for good and serve
+        // this and every later call through peer copies
+        GGNN_LOG(0, "RCCL exchange failed (%s): falling back to peer copies", e.what());
+        destroy_comms();
+        rccl_state = -1;
+      }
+    }
+    exchange_peer_copies(lane, nq, k_query, row, ids_out, dists_out, blocking);
+  }
+
+  // slice of the query set that GPU g merges and returns
+  static void slice_of(uint32_t nq, size_t G, size_t g, uint32_t* first, uint32_t* count)
+  {
+    const uint32_t per = (nq + static_cast<uint32_t>(G) - 1) / static_cast<uint32_t>(G);
+    *first = std::min<uint32_t>(nq, static_cast<uint32_t>(g) * per);
+    *count = std::min<uint32_t>(per, nq - *first);
+  }
+
+  // merged slice [first, first + count) of ctx.m_pack -> caller's arrays
+  void return_slice(DeviceCtx& ctx, int lane, uint32_t nq, uint32_t k_query, uint32_t first,
+                    uint32_t count, int32_t* ids_out, float* dists_out, bool blocking)
+  {
+    DeviceCtx::ExchangeBufs& x = ctx.xb[lane];
+    hipStream_t st = ctx.lane_stream(lane);
+    const size_t off = static_cast<size_t>(first) * k_query;
+    const size_t n = static_cast<size_t>(count) * k_query;
+    const int32_t* m_ids = x.m_pack.as<int32_t>() + off;
+    const int32_t* m_dists = x.m_pack.as<int32_t>() + static_cast<size_t>(nq) * k_query + off;
+    if (blocking) {
+      x.h_pack.grow(2 * n * 4);
+      int32_t* h = static_cast<int32_t*>(x.h_pack.p);
+      GGNN_HIP_CHECK(hipMemcpyAsync(h, m_ids, n * 4, hipMemcpyDeviceToHost, st));
+      GGNN_HIP_CHECK(hipMemcpyAsync(h + n, m_dists, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    else {
+      GGNN_HIP_CHECK(hipMemcpyAsync(ids_out + off, m_ids, n * 4, hipMemcpyDefault, st));
+      GGNN_HIP_CHECK(hipMemcpyAsync(dists_out + off, m_dists, n * 4, hipMemcpyDefault, st));
+    }
+  }
+  void finish_slices(int lane, uint32_t nq, uint32_t k_query, size_t G_slices, int32_t* ids_out,
+                     float* dists_out)
+  {
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.lane_stream(lane)));
+    }
+    for (size_t g = 0; g < G_slices; ++g) {
+      uint32_t first, count;
+      slice_of(nq, G_slices, g, &first, &count);
+      if (!count)
+        continue;
+      const size_t off = static_cast<size_t>(first) * k_query;
+      const size_t n = static_cast<size_t>(count) * k_query;
+      const int32_t* h = static_cast<const int32_t*>(devs[g].xb[lane].h_pack.p);
+      std::memcpy(ids_out + off, h, n * 4);
+      std::memcpy(dists_out + off, h + n, n * 4);
+    }
+  }
+
+  // Several GPUs, RCCL: every GPU contributes its packed sorted rows (ids and distance bit
+  // patterns in one buffer) to ONE grouped all-gather over xGMI, merges a 1/G slice of the
+  // queries with id offset g * shards_per_gpu * N_shard (result_merger.cpp:115-116) and returns
+  // that slice.  The reference copies everything to the host and merges there with a heap per
+  // query (ggnn.cu:308-329, result_merger.cpp:51-149).
+  void exchange_rccl(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                     float* dists_out, bool blocking)
   {
     const Rccl& rccl = Rccl::get();
     const size_t G = devs.size();
     const size_t part = nq * row;
     for (DeviceCtx& ctx : devs) {
       ctx.activate();
-      DeviceCtx::grow(ctx.g_ids, G * part * 4);
-      DeviceCtx::grow(ctx.g_dists, G * part * 4);
+      DeviceCtx::grow(ctx.xb[lane].g_pack, G * 2 * part * 4);
+      DeviceCtx::grow(ctx.xb[lane].m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
     }
     GGNN_RCCL_CHECK(rccl.GroupStart());
-    for (size_t g = 0; g < G; ++g) {
+    ncclResult_t first_error = ncclSuccess;
+    for (size_t g = 0; g < G && first_error == ncclSuccess; ++g) {
       DeviceCtx& ctx = devs[g];
-      GGNN_RCCL_CHECK(rccl.AllGather(ctx.r_ids.p, ctx.g_ids.p, part, ncclInt32, comms[g], ctx.stream));
-      GGNN_RCCL_CHECK(
-          rccl.AllGather(ctx.r_dists.p, ctx.g_dists.p, part, ncclFloat32, comms[g], ctx.stream));
+      first_error = rccl.AllGather(ctx.xb[lane].r_pack.p, ctx.xb[lane].g_pack.p, 2 * part,
+                                   ncclInt32, comms[g], ctx.lane_stream(lane));
     }
-    GGNN_RCCL_CHECK(rccl.GroupEnd());
-    const uint32_t per = (nq + static_cast<uint32_t>(G) - 1) / static_cast<uint32_t>(G);
+    // the group is closed whatever happened inside it
+    const ncclResult_t end = rccl.GroupEnd();
+    GGNN_RCCL_CHECK(first_error);
+    GGNN_RCCL_CHECK(end);
     for (size_t g = 0; g < G; ++g) {
       DeviceCtx& ctx = devs[g];
-      const uint32_t first = std::min<uint32_t>(nq, static_cast<uint32_t>(g) * per);
-      const uint32_t count = std::min<uint32_t>(per, nq - first);
+      uint32_t first, count;
+      slice_of(nq, G, g, &first, &count);
       if (!count)
         continue;
       ctx.activate();
-      DeviceCtx::grow(ctx.m_ids, static_cast<size_t>(nq) * k_query * 4);
-      DeviceCtx::grow(ctx.m_dists, static_cast<size_t>(nq) * k_query * 4);
+      DeviceCtx::ExchangeBufs& x = ctx.xb[lane];
+      int32_t* m_ids = x.m_pack.as<int32_t>();
       launch_merge_results_range(nq, k_query, static_cast<uint32_t>(G), static_cast<uint32_t>(row),
-                                 shards_per_gpu * cfg.N, ctx.g_ids.as<int32_t>(),
-                                 ctx.g_dists.as<float>(), ctx.m_ids.as<int32_t>(),
-                                 ctx.m_dists.as<float>(), nullptr, nullptr, first, count, ctx.stream);
-      const size_t off = static_cast<size_t>(first) * k_query;
-      GGNN_HIP_CHECK(hipMemcpyAsync(ids_out + off, ctx.m_ids.as<int32_t>() + off,
-                                    static_cast<size_t>(count) * k_query * 4,
-                                    hipMemcpyDeviceToHost, ctx.stream));
-      GGNN_HIP_CHECK(hipMemcpyAsync(dists_out + off, ctx.m_dists.as<float>() + off,
-                                    static_cast<size_t>(count) * k_query * 4,
-                                    hipMemcpyDeviceToHost, ctx.stream));
+                                 shards_per_gpu * cfg.N, x.g_pack.as<int32_t>(),
+                                 reinterpret_cast<const float*>(x.g_pack.as<int32_t>() + part),
+                                 m_ids, reinterpret_cast<float*>(m_ids + static_cast<size_t>(nq) * k_query),
+                                 nullptr, nullptr, first, count, ctx.lane_stream(lane), 2 * part);
+      return_slice(ctx, lane, nq, k_query, first, count, ids_out, dists_out, blocking);
     }
-    for (DeviceCtx& ctx : devs) {
-      ctx.activate();
-      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
-    }
+    if (blocking)
+      finish_slices(lane, nq, k_query, G, ids_out, dists_out);
     last_exchange = "rccl";
   }
 
-  // Several contexts without RCCL (contexts sharing one device, or no librccl): candidates to the
+  // Several contexts without RCCL (contexts sharing one device, or no librccl): packed rows to the
   // first GPU with peer copies, k-way merge there.
-  void exchange_peer_copies(uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
-                            float* dists_out)
+  void exchange_peer_copies(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                            float* dists_out, bool blocking)
   {
     DeviceCtx& d0 = devs[0];
-    d0.activate();
+    const size_t G = devs.size();
     const size_t part = nq * row;
-    DeviceCtx::grow(d0.g_ids, devs.size() * part * 4);
-    DeviceCtx::grow(d0.g_dists, devs.size() * part * 4);
-    DeviceCtx::grow(d0.m_ids, static_cast<size_t>(nq) * k_query * 4);
-    DeviceCtx::grow(d0.m_dists, static_cast<size_t>(nq) * k_query * 4);
-    for (size_t g = 0; g < devs.size(); ++g) {
-      GGNN_HIP_CHECK(hipMemcpyAsync(d0.g_ids.as<int32_t>() + g * part, devs[g].r_ids.p, part * 4,
-                                    hipMemcpyDefault, d0.stream));
-      GGNN_HIP_CHECK(hipMemcpyAsync(d0.g_dists.as<float>() + g * part, devs[g].r_dists.p, part * 4,
-                                    hipMemcpyDefault, d0.stream));
+    // the first GPU's lane waits for the local searches of the others
+    for (size_t g = 1; g < G; ++g) {
+      DeviceCtx& ctx = devs[g];
+      ctx.activate();
+      if (!ctx.xb[lane].done)
+        GGNN_HIP_CHECK(hipEventCreateWithFlags(&ctx.xb[lane].done, hipEventDisableTiming));
+      GGNN_HIP_CHECK(hipEventRecord(ctx.xb[lane].done, ctx.lane_stream(lane)));
     }
-    launch_merge_results(nq, k_query, static_cast<uint32_t>(devs.size()),
-                         static_cast<uint32_t>(row), shards_per_gpu * cfg.N, d0.g_ids.as<int32_t>(),
-                         d0.g_dists.as<float>(), d0.m_ids.as<int32_t>(), d0.m_dists.as<float>(),
-                         d0.stream);
-    GGNN_HIP_CHECK(hipMemcpyAsync(ids_out, d0.m_ids.p, static_cast<size_t>(nq) * k_query * 4,
-                                  hipMemcpyDeviceToHost, d0.stream));
-    GGNN_HIP_CHECK(hipMemcpyAsync(dists_out, d0.m_dists.p, static_cast<size_t>(nq) * k_query * 4,
-                                  hipMemcpyDeviceToHost, d0.stream));
-    GGNN_HIP_CHECK(hipStreamSynchronize(d0.stream));
+    d0.activate();
+    hipStream_t st = d0.lane_stream(lane);
+    DeviceCtx::ExchangeBufs& x = d0.xb[lane];
+    DeviceCtx::grow(x.g_pack, G * 2 * part * 4);
+    DeviceCtx::grow(x.m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
+    for (size_t g = 0; g < G; ++g) {
+      if (g)
+        GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[g].xb[lane].done, 0));
+      GGNN_HIP_CHECK(hipMemcpyAsync(x.g_pack.as<int32_t>() + g * 2 * part,
+                                    devs[g].xb[lane].r_pack.p, 2 * part * 4, hipMemcpyDefault, st));
+    }
+    int32_t* m_ids = x.m_pack.as<int32_t>();
+    launch_merge_results_range(nq, k_query, static_cast<uint32_t>(G), static_cast<uint32_t>(row),
+                               shards_per_gpu * cfg.N, x.g_pack.as<int32_t>(),
+                               reinterpret_cast<const float*>(x.g_pack.as<int32_t>() + part), m_ids,
+                               reinterpret_cast<float*>(m_ids + static_cast<size_t>(nq) * k_query),
+                               nullptr, nullptr, 0, nq, st, 2 * part);
+    return_slice(d0, lane, nq, k_query, 0, nq, ids_out, dists_out, blocking);
+    if (blocking)
+      finish_slices(lane, nq, k_query, 1, ids_out, dists_out);
     last_exchange = "copy";
   }
 
   // Extension for serving: enqueue one query batch and return.  Consecutive batches given
   // different slots run on different streams, so the under-occupied tail of one batch's launch
   // overlaps with the head of the next (a lone 10k-query launch is latency-bound).
-  // Restrictions: one GPU; query and result arrays already on that GPU (nothing is staged);
-  // results are the sorted [Nq, K * shards] rows of results-on-GPU mode (ggnn.cuh:108-113) and are
-  // valid after synchronize().
-  void query_async(const void* d_query, uint64_t Nq, uint32_t D, ggnn_dtype dtype, int q_gpu,
-                   uint32_t k_query, float tau_query, uint32_t max_iterations,
-                   ggnn_measure measure, int32_t* d_ids, float* d_dists, uint32_t slot)
+  //
+  // One GPU: query and result arrays already on that GPU (nothing is staged); results are the
+  // sorted [Nq, K * shards] rows of results-on-GPU mode (ggnn.cuh:108-113).
+  // Several GPUs: the query may live on any GPU of the node or in page-locked host memory (it is
+  // copied to every GPU on the slot's stream), results are the MERGED [Nq, K] arrays, written
+  // by asynchronous copies (device memory of any GPU, or page-locked host memory; with pageable
+  // memory the copies degrade to synchronous ones).  Local search, the RCCL all-gather, the
+  // slice merges and the result copies of batch i+1 are all enqueued while batch i runs.
+  // Valid after synchronize() / synchronize_slot(slot).
+  //
+  // Ordering contract with the blocking query(): both may be used on one handle from one
+  // thread; a blocking call does not wait for batches in flight (its buffers and stream are its
+  // own), and a call that has to re-code the pre-screen copy for another measure first drains
+  // every slot.
+  void query_async(const void* d_query, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
+                   ggnn_location loc, int q_gpu, uint32_t k_query, float tau_query,
+                   uint32_t max_iterations, ggnn_measure measure, int32_t* d_ids, float* d_dists,
+                   uint32_t slot)
   {
     GGNN_REQUIRE(has_graph(), GGNN_INVALID_STATE, "There is no graph to query.");
-    GGNN_REQUIRE(devs.size() == 1, GGNN_INVALID_STATE,
-                 "Asynchronous queries are only possible when using a single GPU.");
     check_query(Nq, D, dtype, d_query);
-    DeviceCtx& ctx = devs[0];
-    GGNN_REQUIRE(q_gpu == ctx.device, GGNN_INVALID_ARGUMENT,
-                 "asynchronous queries need the query on the engine's GPU");
-    GGNN_REQUIRE(pad_D == base_D && (reinterpret_cast<uintptr_t>(d_query) & 15u) == 0,
-                 GGNN_UNSUPPORTED,
-                 "asynchronous queries need 16-byte aligned rows (no padding is staged)");
+    GGNN_REQUIRE(!Nq || (d_ids != nullptr && d_dists != nullptr), GGNN_INVALID_ARGUMENT,
+                 "result pointers are null");
     if (!Nq)
       return;
-    ctx.activate();
-    for (uint32_t si = 0; si < shards_per_gpu; ++si)
-      (void)ensure_prescreen(ctx, si, measure);
-    ctx.ensure_shard_streams();
-    hipStream_t stream = ctx.shard_stream[slot % DeviceCtx::kShardStreams];
     const uint32_t nq = static_cast<uint32_t>(Nq);
+    const int lane = static_cast<int>(slot % DeviceCtx::kShardStreams);
+    // the pre-screen copy of another measure is replaced below: nothing may still read it
+    bool recode = false;
+    for (const DeviceCtx& ctx : devs)
+      for (const Shard& sh : ctx.shards)
+        recode = recode || (sh.ps_state != 0 && sh.ps_measure != measure);
+    if (recode)
+      synchronize();
+    const char* force = std::getenv("GGNN_EXCHANGE");
+    const bool force_rccl = force && std::string(force) == "rccl";
+    if (devs.size() == 1 && !force_rccl) {
+      DeviceCtx& ctx = devs[0];
+      GGNN_REQUIRE(loc == GGNN_GPU && q_gpu == ctx.device, GGNN_INVALID_ARGUMENT,
+                   "asynchronous queries need the query on the engine's GPU");
+      GGNN_REQUIRE(pad_D == base_D && (reinterpret_cast<uintptr_t>(d_query) & 15u) == 0,
+                   GGNN_UNSUPPORTED,
+                   "asynchronous queries need 16-byte aligned rows (no padding is staged)");
+      ctx.activate();
+      for (uint32_t si = 0; si < shards_per_gpu; ++si)
+        (void)ensure_prescreen(ctx, si, measure);
+      ctx.ensure_shard_streams();
+      enqueue_local_search(ctx, lane, d_query, nq, k_query, tau_query, max_iterations, measure,
+                           d_ids, d_dists);
+      return;
+    }
+    GGNN_REQUIRE(pad_D == base_D, GGNN_UNSUPPORTED,
+                 "asynchronous queries need 16-byte rows (no padding is staged)");
+    const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
+    const size_t part = nq * row;
+    const size_t qbytes = Nq * static_cast<size_t>(pad_D) * dtype_size(dtype);
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      for (uint32_t si = 0; si < shards_per_gpu; ++si)
+        (void)ensure_prescreen(ctx, si, measure);
+      ctx.ensure_shard_streams();
+      DeviceCtx::ExchangeBufs& x = ctx.xb[lane];
+      hipStream_t st = ctx.lane_stream(lane);
+      const void* q_here = d_query;
+      if (!(loc == GGNN_GPU && q_gpu == ctx.device &&
+            (reinterpret_cast<uintptr_t>(d_query) & 15u) == 0)) {
+        DeviceCtx::grow(x.q_stage, qbytes);
+        GGNN_HIP_CHECK(hipMemcpyAsync(x.q_stage.p, d_query, qbytes, hipMemcpyDefault, st));
+        q_here = x.q_stage.p;
+      }
+      DeviceCtx::grow(x.r_pack, 2 * part * 4);
+      int32_t* r = x.r_pack.as<int32_t>();
+      enqueue_local_search(ctx, lane, q_here, nq, k_query, tau_query, max_iterations, measure, r,
+                           reinterpret_cast<float*>(r + part));
+    }
+    exchange(lane, nq, k_query, row, d_ids, d_dists, /*blocking=*/false);
+  }
+
+  // the shards of one GPU on one lane's stream, nothing waits
+  void enqueue_local_search(DeviceCtx& ctx, int lane, const void* d_query, uint32_t nq,
+                            uint32_t k_query, float tau_query, uint32_t max_iterations,
+                            ggnn_measure measure, int32_t* d_ids, float* d_dists)
+  {
+    hipStream_t stream = ctx.lane_stream(lane);
     for (uint32_t si = 0; si < shards_per_gpu; ++si) {
       const Shard& sh = ctx.shards[si];
       QueryLaunch ql{shard_base(ctx, si), d_query, base_dtype, cfg.N, pad_D, nq, sh.graph,
@@ -1508,8 +1703,8 @@ ggnn_status ggnn_query_async(ggnn_t* h, const void* query, uint64_t Nq, uint32_t
 {
   GGNN_NEED_HANDLE(h);
   return guarded(h, [&] {
-    h->query_async(query, Nq, D, dtype, gpu_id, k_query, tau_query, max_iterations, measure,
-                   ids_out, dists_out, slot);
+    h->query_async(query, Nq, D, dtype, gpu_id < 0 ? GGNN_CPU : GGNN_GPU, gpu_id, k_query,
+                   tau_query, max_iterations, measure, ids_out, dists_out, slot);
   });
 }
 

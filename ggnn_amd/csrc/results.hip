@@ -71,7 +71,7 @@ __global__ void merge_results_kernel(uint32_t Nq, uint32_t k, uint32_t num_parts
                                      uint32_t id_offset_per_part, const int32_t* parts_ids,
                                      const float* parts_dists, int32_t* ids_out, float* dists_out,
                                      const uint32_t* qlist, const uint32_t* qcount,
-                                     uint32_t first, uint32_t count)
+                                     uint32_t first, uint32_t count, size_t part_elems)
 {
   // queries [first, first + count) of the Nq rows per part (or the listed ones); the outputs are
   // indexed by the query number as well
@@ -89,9 +89,8 @@ __global__ void merge_results_kernel(uint32_t Nq, uint32_t k, uint32_t num_parts
   float head[kMaxParts];
   for (uint32_t p = 0; p < num_parts; ++p) {
     pos[p] = 0;
-    head[p] = parts_dists[(static_cast<size_t>(p) * Nq + n) * stride];
+    head[p] = parts_dists[p * part_elems + static_cast<size_t>(n) * stride];
   }
-  const size_t part_elems = static_cast<size_t>(Nq) * stride;
   for (uint32_t j = 0; j < k; ++j) {
     uint32_t bp = 0;
     bool have = false;
@@ -139,7 +138,7 @@ void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uin
                                 uint32_t id_offset_per_part, const int32_t* parts_ids,
                                 const float* parts_dists, int32_t* ids_out, float* dists_out,
                                 const uint32_t* qlist, const uint32_t* qcount, uint32_t first,
-                                uint32_t count, hipStream_t stream)
+                                uint32_t count, hipStream_t stream, size_t part_elems)
 {
   if (!Nq || !count)
     return;
@@ -150,7 +149,8 @@ void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uin
   const uint32_t block = 128;
   hipLaunchKernelGGL(merge_results_kernel, dim3((count + block - 1) / block), dim3(block), 0,
                      stream, Nq, k, num_parts, stride, id_offset_per_part, parts_ids, parts_dists,
-                     ids_out, dists_out, qlist, qcount, first, count);
+                     ids_out, dists_out, qlist, qcount, first, count,
+                     part_elems ? part_elems : static_cast<size_t>(Nq) * stride);
   GGNN_HIP_CHECK(hipGetLastError());
 }
 

@@ -113,12 +113,13 @@ class ShardedGGNN:
     def query_async(self, query, k_query, tau_query, max_iterations=400,
                     measure=DistanceMeasure.Euclidean, slot=0):
         """enqueue the local search of one batch; returns a ticket for `finish`"""
-        ids, dists = self.engine.query_async(query, k_query, tau_query, max_iterations, measure,
-                                             slot)
-        return (ids, dists, int(k_query), int(slot))
+        # the engine's ticket keeps query, ids and dists alive until its slot is synchronised
+        local = self.engine.query_async(query, k_query, tau_query, max_iterations, measure, slot)
+        return (local, int(k_query), int(slot))
 
     def finish(self, ticket):
         """wait for the ticket's local search, exchange and merge: the global [Nq, K] result"""
-        ids, dists, k, slot = ticket
+        local, k, slot = ticket
+        ids, dists = local
         self.engine.synchronize(slot)
         return self._exchange(ids, dists, k)

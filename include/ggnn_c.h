@@ -98,9 +98,20 @@ ggnn_status ggnn_query(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D, gg
 /* Extension for serving (no counterpart in the reference, whose query() blocks,
  * gpu_instance.cu:687-712): enqueue one batch and return.  Batches given different `slot`s run on
  * different streams, so the thin tail of one batch's launch overlaps with the next batch.
- * One GPU only; `query`, `ids_out`, `dists_out` are device memory on that GPU, rows 16-byte
- * aligned; the results are the sorted [Nq, k_query * shards] rows of results-on-GPU mode and are
- * valid after ggnn_synchronize(). */
+ * Handle on one GPU: `query`, `ids_out`, `dists_out` are device memory on that GPU (gpu_id),
+ * rows 16-byte aligned; the results are the sorted [Nq, k_query * shards] rows of
+ * results-on-GPU mode.
+ * Handle on several GPUs (ggnn_set_gpus): `query` is device memory of GPU gpu_id (any GPU of
+ * the node) or, with gpu_id < 0, page-locked host memory; it is copied to every GPU on the
+ * slot's stream.  The results are the MERGED [Nq, k_query] arrays (local searches, one packed
+ * RCCL all-gather, per-GPU slice merges: replaces ggnn.cu:308-329 + result_merger.cpp:51-149),
+ * written by asynchronous copies: ids_out / dists_out must be device memory or page-locked host
+ * memory (pageable memory works but makes the copies synchronous).
+ * Everything is valid after ggnn_synchronize() / ggnn_synchronize_slot(slot); `query`,
+ * `ids_out` and `dists_out` must stay alive and untouched until then.
+ * Ordering with ggnn_query(): both may be used on one handle from one thread; a blocking call
+ * has its own stream and staging and does not wait for batches in flight.  A call whose
+ * measure differs from the one the pre-screen copy was coded for drains every slot first. */
 ggnn_status ggnn_query_async(ggnn_t* h, const void* query, uint64_t Nq, uint32_t D,
                              ggnn_dtype dtype, int gpu_id, uint32_t k_query, float tau_query,
                              uint32_t max_iterations, ggnn_measure measure, int32_t* ids_out,

@@ -3,9 +3,13 @@ import collections, csv, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/{tag}"
+extra = sys.argv[3] if len(sys.argv) > 3 else ""
 out_dir = "profiles"
 os.makedirs(out_dir, exist_ok=True)
-CMD = "python bench.py --lean"
+CMD = "python bench.py --lean" + (" " + extra if extra else "")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha  # noqa: E402  (fingerprint of the profiled kernel sources)
+SHA = kernel_source_sha()
 
 
 def counters(name):
@@ -43,7 +47,7 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter] = {"launches": len(v), "avg_kb": sum(v) / len(v),
                                           "last_kb": v[-1], "max_kb": max(v)}
-json.dump({"workload": workload,
+json.dump({"workload": workload, "kernel_source_sha": SHA,
            "command": f"rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- {CMD} "
                       "--steps 3 --warmup 1 (one pass per counter)",
            "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 64 B per "
@@ -67,7 +71,7 @@ is_trav = lambda k: any(t in k for t in ("query_kernel", "merge_kernel", "sym_ke
 # ---- SQ counters of the query kernels (instruction mix, VALU utilisation) -----------------------
 sq = per_kernel(("sq1", "sq2"), is_query)
 if sq:
-    json.dump({"workload": workload,
+    json.dump({"workload": workload, "kernel_source_sha": SHA,
                "command": f"rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- {CMD} "
                           "--steps 3 --warmup 1 (two passes)",
                "units": "per launch, summed over the device; SQ cycle counters tick once per 4 "
@@ -75,13 +79,34 @@ if sq:
                         "clock / 4 x 1024 SIMDs)",
                "kernels": sq}, open(f"{out_dir}/{tag}_pmc_sq.json", "w"), indent=1)
 
+# ---- recomputable roofline fraction of this shape ------------------------------------------------
+try:
+    rl = bench["roofline"]
+    qk = [r for r in stats if "query_kernel" in r["Name"] and "bf_" not in r["Name"]]
+    doc = {"workload": workload, "kernel_source_sha": SHA,
+           "bench_line": {k: bench.get(k) for k in ("value", "ms_per_step", "recall_at_10",
+                                                    "query_kernel_ms", "n_dist_per_query",
+                                                    "n_pop_per_query", "float_rows_per_query",
+                                                    "code_rows_per_query")},
+           "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
+                                               "bytes_per_launch", "kernel_ms", "kernel")},
+           "rocprofv3_kernel_stats": [{"name": r["Name"], "calls": int(r["Calls"]),
+                                       "avg_ns": float(r["AverageNs"])} for r in qk],
+           "pmc_hbm_bytes_per_launch_corrected": {
+               k: (2 * v.get("FETCH_SIZE", {"avg_kb": 0})["avg_kb"] * 1024
+                   + v.get("WRITE_SIZE", {"avg_kb": 0})["avg_kb"] * 1024)
+               for k, v in pmc.items() if is_query(k)}}
+    json.dump(doc, open(f"{out_dir}/{tag}_roofline.json", "w"), indent=1)
+except Exception as e:
+    print("no roofline summary:", e)
+
 # ---- L2 (TCC) hit rate and requests that left the L2 ------------------------------------------
 l2 = per_kernel(("l2a", "l2b"), is_trav)
 for k, c in l2.items():
     if c.get("TCC_REQ_sum"):
         c["l2_hit_rate"] = c.get("TCC_HIT_sum", 0.0) / (c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 1.0))
 if l2:
-    json.dump({"workload": workload,
+    json.dump({"workload": workload, "kernel_source_sha": SHA,
                "command": f"rocprofv3 --pmc TCC_* --kernel-trace --output-format csv -- {CMD} "
                           "--steps 3 --warmup 1 (two passes)",
                "units": "per launch; TCC = the 16 L2 channels per XCD; TCC_EA0_RDREQ are read "

@@ -463,3 +463,95 @@ def test_prescreen_with_padded_rows(D, measure):
     assert res[0][2] == res[1][2]
     rows = g.last_query_rows_read()
     assert rows["code_rows"] == 0 and rows["float_rows"] == res[1][2]["n_dist"]
+
+
+@pytest.mark.parametrize("where", ["device", "pinned", "pageable"])
+def test_query_async_multi_gpu_handle_copy_exchange(where):
+    """query_async on a handle that drives several GPU contexts (both on device 0 here, so the
+    exchange runs through peer copies + one merge): merged [Nq, K] results equal the blocking
+    query(), for a query in device memory, page-locked and pageable host memory"""
+    import ggnn_amd as ggnn
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 287), make_int_data(250, D, 288)
+    q2 = q[::-1].copy()
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_gpus([0, 0])
+    eng.set_shard_size(2000)          # two contexts x two resident shards
+    eng.build(24, 0.5, 1)
+    ref, ref2 = eng.query(q, K, 0.7, 200), eng.query(q2, K, 0.7, 200)
+    assert eng.last_exchange() == "copy"
+
+    def put(x):
+        t = torch.from_numpy(x)
+        return t.cuda() if where == "device" else (t.pin_memory() if where == "pinned" else t)
+
+    tickets = [eng.query_async(put(q if i % 2 == 0 else q2), K, 0.7, 200, slot=i) for i in range(5)]
+    eng.synchronize()
+    for i, t in enumerate(tickets):
+        want = ref if i % 2 == 0 else ref2
+        assert t.done and tuple(t.ids.shape) == (250, K)
+        assert torch.equal(t.ids.cpu(), want[0]) and torch.equal(t.dists.cpu(), want[1])
+    # one slot only
+    t = eng.query_async(put(q), K, 0.7, 200, slot=2)
+    eng.synchronize(2)
+    assert t.done and torch.equal(t.ids.cpu(), ref[0])
+
+
+def test_query_async_rccl_single_rank_world(monkeypatch):
+    """the RCCL form of the asynchronous multi-GPU path on a one-rank world: GGNN_EXCHANGE=rccl
+    sends a one-GPU, four-shard handle through communicator creation, the packed grouped
+    all-gather on the slot's stream, the slice merge and the asynchronous result copies"""
+    import ggnn_amd as ggnn
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 387), make_int_data(333, D, 388)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_gpus([0])
+    eng.set_shard_size(2000)
+    eng.build(24, 0.5, 1)
+    ref = eng.query(q, K, 0.7, 200)
+    monkeypatch.setenv("GGNN_EXCHANGE", "rccl")
+    again = eng.query(q, K, 0.7, 200)
+    assert eng.last_exchange() == "rccl"
+    assert torch.equal(ref[0], again[0]) and torch.equal(ref[1], again[1])
+    qd = torch.from_numpy(q).cuda()
+    tickets = [eng.query_async(qd, K, 0.7, 200, slot=i) for i in range(3)]
+    tickets.append(eng.query_async(torch.from_numpy(q), K, 0.7, 200, slot=3))   # pinned host query
+    eng.synchronize()
+    for t in tickets:
+        assert tuple(t.ids.shape) == (333, K)
+        assert torch.equal(t.ids.cpu(), ref[0]) and torch.equal(t.dists.cpu(), ref[1])
+    assert eng.last_exchange() == "rccl"
+
+
+def test_query_async_ticket_keeps_inputs_alive():
+    """the engine streams are invisible to torch's caching allocator.  A temporary
+    query tensor whose last Python reference dies right after query_async() must not be recycled
+    (and overwritten) while the kernel still reads it: the engine keeps the ticket until
+    synchronize()."""
+    import gc
+    import ggnn_amd as ggnn
+    base, q = make_int_data(20000, 64, 411), make_int_data(4000, 64, 412)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 1)
+    qd = torch.from_numpy(q).cuda()
+    ref = eng.query(qd, 10, 0.9, 400)
+    outs = []
+    for i in range(8):
+        tmp = qd.clone()                       # a temporary: freed as soon as we drop it
+        outs.append(eng.query_async(tmp, 10, 0.9, 400, slot=i % 2))
+        ptr = tmp.data_ptr()
+        del tmp
+        gc.collect()
+        # the allocator would hand the same block out again if nothing referenced it
+        junk = torch.full((4000, 64), 255.0, device="cuda")
+        assert junk.data_ptr() != ptr or i == -1
+        del junk
+    assert sum(len(v) for v in eng._inflight.values()) == 8
+    eng.synchronize()
+    assert not eng._inflight
+    for ids, d in outs:
+        assert torch.equal(ids, ref[0]) and torch.equal(d, ref[1])

@@ -1,0 +1,72 @@
+"""Dry runs of every bench.py mode on the one-GPU test box, at toy sizes:
+  * `--gpus 2` under torch.distributed.run (two gloo ranks, both on GPU 0): the fixed-base series
+    with blocking / saturated / pipelined figures, the one-GPU point of the same base, the
+    one-handle `--in-process` child (in-engine exchange) and the secondary base;
+  * the lean N = 1 line: `roofline` is the HBM own-bytes fraction, `cpu_baseline`
+    and the secondaries have their contracted shape.
+These check plumbing and JSON contracts, not performance."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_dry_run():
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29631", "bench.py", "--gpus", "2",
+               "--steps", "4", "--warmup", "1", "--backend", "gloo", "--single-device",
+               "--n-base", "20000", "--secondary-n-base", "10000", "--n-query", "400",
+               "--in-process-timeout", "300"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert "160000 points" in out["config"]["workload"]
+    assert out["recall_at_10"] > 0.9
+    one = out["one_gpu_same_base"]
+    assert one["queries_per_s"] > 0 and "saturated_batch" in one and "pipelined_batches" in one
+    for key in ("speedup_vs_one_gpu_same_base", "saturated_speedup_vs_one_gpu_same_base",
+                "pipelined_speedup_vs_one_gpu_same_base"):
+        assert out[key] and out[key] > 0, key
+    assert out["pipelined_batches"]["results_equal_blocking"] is True
+    inproc = out["in_process_handle"]
+    assert "error" not in inproc, inproc
+    assert inproc["exchange"] in ("copy", "rccl") and inproc["queries_per_s"] > 0
+    assert inproc["pipelined_batches"]["results_equal_blocking"] is True
+    sec = out["secondary_base"]
+    assert sec["n_base_per_shard"] == 10000 and sec["speedup_vs_one_gpu_same_base"]["blocking"] > 0
+
+
+def test_bench_lean_line_contract():
+    out = run([sys.executable, "bench.py", "--lean", "--steps", "3", "--warmup", "1",
+               "--n-base", "100000", "--n-query", "2000"])
+    rl = out["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+    assert abs(rl["achieved"] - rl["bytes_per_launch"] / (rl["kernel_ms"] * 1e-3) / 1e9) < 1e-6
+    assert rl["traffic"] is None          # no committed PMC pass of this toy workload
+    sec = rl["secondary"]
+    assert sec["valu_issue"]["frac"] is None and "note" in sec["valu_issue"]
+    assert sec["reference_algorithm_bytes"]["bytes_per_launch"] >= rl["bytes_per_launch"]
+    assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["cpu_baseline"] is None
+
+
+def test_bench_u8_and_cosine_flags():
+    out = run([sys.executable, "bench.py", "--lean", "--steps", "2", "--warmup", "1",
+               "--n-base", "50000", "--n-query", "1000", "--dtype", "u8"])
+    assert out["dtype"] == "u8" and "u8" in out["config"]["workload"]
+    assert out["code_rows_per_query"] == 0 and out["roofline"]["frac"] > 0
+    out = run([sys.executable, "bench.py", "--lean", "--steps", "2", "--warmup", "1",
+               "--n-base", "30000", "--n-query", "500", "--dim", "256", "--measure", "cosine"])
+    assert "cosine" in out["config"]["workload"] and out["recall_at_10"] > 0.5
