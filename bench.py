@@ -79,7 +79,11 @@ def synthetic(kind, n, d, seed, device):
 
 def engine_clock_hz(device):
     """engine clock the device reports (kHz -> Hz); SQ cycle counters tick once per 4 clocks"""
-    return float(torch.cuda.get_device_properties(device).clock_rate) * 1e3
+    import ctypes as C
+    from ggnn_amd._lib import check, lib
+    hz = C.c_double()
+    check(lib().ggnn_device_clock_hz(device.index or 0, C.byref(hz)))
+    return float(hz.value)
 
 
 KERNEL_SOURCES = ("traversal.hpp", "query.hip", "common.hpp", "prescreen.hip")

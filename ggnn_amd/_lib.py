@@ -87,6 +87,7 @@ SIGNATURES = {
     "ggnn_set_build_hooks": (_int, [_vp, _vp, _u64, _int]),
     "ggnn_get_shard_layout": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_last_query_rows_read": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "ggnn_device_clock_hz": (_int, [_int, C.POINTER(C.c_double)]),
     "ggnn_set_log_level": (None, [_int]),
     "ggnn_graph_config_init": (_int, [_u32, _u32, _u32, _cfgp]),
     "ggnn_query_sizing": (_int, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),

@@ -1662,6 +1662,16 @@ ggnn_status ggnn_build(ggnn_t* h, uint32_t k_build, float tau_build,
   return guarded(h, [&] { h->build(k_build, tau_build, refinement_iterations, measure); });
 }
 
+ggnn_status ggnn_device_clock_hz(int device, double* clock_hz)
+{
+  return guarded(nullptr, [&] {
+    GGNN_REQUIRE(clock_hz != nullptr, GGNN_INVALID_ARGUMENT, "null output");
+    int khz = 0;
+    GGNN_HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, device));
+    *clock_hz = static_cast<double>(khz) * 1e3;
+  });
+}
+
 ggnn_status ggnn_set_build_hooks(ggnn_t* h, const float* rng, uint64_t n_rng, int serial_sym)
 {
   GGNN_NEED_HANDLE(h);

@@ -183,6 +183,9 @@ ggnn_status ggnn_set_build_hooks(ggnn_t* h, const float* rng, uint64_t n_rng, in
  * ggnn.cu:299-306) and points per shard.  GGNN_INVALID_STATE without a graph. */
 ggnn_status ggnn_get_shard_layout(const ggnn_t* h, uint32_t* num_shards, uint32_t* shards_per_gpu,
                                   uint32_t* n_shard);
+/* tracing: peak engine clock the device reports (hipDeviceAttributeClockRate), in Hz; used to
+ * turn SQ cycle counters into utilisation figures instead of assuming a nominal clock */
+ggnn_status ggnn_device_clock_hz(int device, double* clock_hz);
 /* nanobind.cu:151 set_log_level */
 void ggnn_set_log_level(int level);
 
