@@ -1,0 +1,37 @@
+// Shared between bf_mfma.hip (f32 / LDS-list kernels, host side) and bf_i8.hip (the register-set
+// uint8 kernel, compiled with the VGPR form of the MFMA instructions).
+#pragma once
+#include "traversal.hpp"
+
+namespace ggnn_amd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBfQueriesPerBlock = 128;
+constexpr int kBfTileRows = 32;
+constexpr uint32_t kBfMaxKP = 120;  // lists of 128 queries must fit into LDS next to the tiles
+
+struct BfMfmaArgs {
+  const void* base;
+  const void* query;
+  const float* mean;   // [D] shift applied to base and query rows (float32 squared L2), or null
+  const float* bnorm;
+  const float* qnorm;
+  int32_t* part_ids;   // [slices][Nq][KP]
+  float* part_dists;   // [slices][Nq][KP]
+  uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
+  uint32_t DM;  // floats of the shift vector kept in LDS by the chunked kernel (D rounded up)
+  uint32_t* gthr;  // i8 v2 kernel: per-query bound shared by all slices (float bits), or null
+};
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kBfI8RowStride = 144;
+
+// bf_i8.hip: launches bf_i8v2_kernel for KP in {4, 10, 16} (an optional seeding launch over the
+// head of the base first); m.gthr must point to Nq words initialised to +inf bits
+void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t warm_rows,
+                    hipStream_t stream);
+size_t bf_i8v2_lds_bytes();
+
+}  // namespace ggnn_amd

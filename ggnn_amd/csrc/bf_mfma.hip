@@ -36,27 +36,9 @@
 //   preceded by KP > K rows of its own slice in exact (distance, index) order: nothing to check.
 #include <cstdlib>
 
-#include "traversal.hpp"
+#include "bf_common.hpp"
 
 namespace ggnn_amd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kBfQueriesPerBlock = 128;
-constexpr int kBfTileRows = 32;
-constexpr uint32_t kBfMaxKP = 120;  // lists of 128 queries must fit into LDS next to the tiles
-
-struct BfMfmaArgs {
-  const void* base;
-  const void* query;
-  const float* mean;   // [D] shift applied to base and query rows (float32 squared L2), or null
-  const float* bnorm;
-  const float* qnorm;
-  int32_t* part_ids;   // [slices][Nq][KP]
-  float* part_dists;   // [slices][Nq][KP]
-  uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
-  uint32_t DM;  // floats of the shift vector kept in LDS by the chunked kernel (D rounded up)
-};
 
 // ---- 1. squared norms ---------------------------------------------------------------------------
 // SHIFT (uint8 only): norms of x - 128, the values the i8 matrix path works on; squared L2
@@ -73,13 +55,24 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
   using Chunk = typename ChunkOf<BaseT>::type;
   const uint32_t g = threadIdx.x & 15;
   float vmax = 0.f;
-  // grid-stride over groups of 16 rows (one row per 16 lanes, 16 bytes per lane and step)
-  for (uint64_t row = static_cast<uint64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); row < N;
-       row += static_cast<uint64_t>(gridDim.x) * 16) {
-    const BaseT* p = data + row * D;
-    float acc = 0.f;
+  // grid-stride over groups of 16 rows (one row per 16 lanes, 16 bytes per lane and step), four
+  // groups per iteration: with one row in flight per lane the kernel ran at the latency of its
+  // loads (0.38 ms for 1M x 128 bytes)
+  constexpr int U = 4;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 16;
+  for (uint64_t row0 = static_cast<uint64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4); row0 < N;
+       row0 += U * stride) {
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      acc[u] = 0.f;
     for (uint32_t e0 = g * EPC; e0 < D; e0 += 16 * EPC) {
-      const Chunk v = *reinterpret_cast<const Chunk*>(p + e0);
+      Chunk v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t row = row0 + u * stride;
+        v[u] = *reinterpret_cast<const Chunk*>(data + (row < N ? row : row0) * D + e0);
+      }
       float m[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e)
@@ -91,15 +84,23 @@ __global__ void __launch_bounds__(256) row_norms_kernel(const BaseT* data, uint3
         }
       }
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float x = ChunkOf<BaseT>::get(v, e) - m[e];
-        acc = fmaf(x, x, acc);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float x = ChunkOf<BaseT>::get(v[u], e) - m[e];
+          acc[u] = fmaf(x, x, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t row = row0 + u * stride;
+      const float a = group_sum<16>(acc[u]);
+      if (row < N) {
+        if (g == 0)
+          out[row] = a;
+        vmax = fmaxf(vmax, a);
       }
     }
-    acc = group_sum<16>(acc);
-    if (g == 0)
-      out[row] = acc;
-    vmax = fmaxf(vmax, acc);
   }
   if (max_out) {
     // one atomic per wave (a million atomics on one address take milliseconds)
@@ -748,9 +749,6 @@ __global__ void __launch_bounds__(256)
 // bytes (row stride 144: conflict-free ds_read_b128, the spare bytes hold the row's norm); four
 // tiles are staged per barrier.  With 4 MFMAs per tile the kernel is bound by staging and the
 // candidate test, not by the matrix pipe.
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t kBfI8RowStride = 144;
 
 constexpr int kBfI8Tiles = 4;  // 32-row tiles per staged block (one barrier per 128 base rows)
 
@@ -1040,13 +1038,22 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   keep_pool_memory(stream);
   // a few more candidates than K per slice: makes the certificate (top of this file) succeed for
   // all but near-degenerate queries; correctness does not depend on the value
-  const uint32_t KP = a.k_query + 8;
+  // uint8 + squared L2 with rows of up to 128 bytes: integer contraction on the i8 matrix path;
+  // lists of up to 24 entries live in registers (bf_i8v2_kernel), longer ones in LDS
+  // (bf_mfma_i8_kernel; GGNN_BF_I8_V1=1 forces that one: A/B hook)
+  const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
+                      std::getenv("GGNN_BF_NO_I8") == nullptr;
+  const bool use_i8v2 = use_i8 && a.k_query <= 16 && std::getenv("GGNN_BF_I8_V1") == nullptr;
+  // (integer arithmetic needs no certificate margin: the register sets hold exactly K rounded up)
+  const uint32_t KP = use_i8v2 ? (a.k_query <= 4 ? 4u : a.k_query <= 10 ? 10u : 16u)
+                               : a.k_query + 8;
   // one chunk of 2*Dh columns when the row fits (D <= 128), otherwise chunks of 128 columns
   // half-row width: 64 when D > 128 (K streams in chunks), otherwise 32 / 48 / 64 so that the
   // single chunk covers the row (columns past D are zero in the tile and in the query operand)
   const uint32_t Dh = a.D > 128 ? 64 : (a.D <= 64 ? 32 : a.D <= 96 ? 48 : 64);
   const uint32_t DP = (2 * Dh) + (((2 * Dh) % 8 == 0) ? 4 : 8);  // odd number of 16-B slots/row
-  const uint32_t qblocks = (a.Nq + kBfQueriesPerBlock - 1) / kBfQueriesPerBlock;
+  const uint32_t queries_per_block = use_i8v2 ? 256u : static_cast<uint32_t>(kBfQueriesPerBlock);
+  const uint32_t qblocks = (a.Nq + queries_per_block - 1) / queries_per_block;
   // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
   // second round costs more than the lower parallelism (measured: 790 blocks 39.8 ms, 474 blocks
   // 31.5 ms for 10k x 1M x 128)
@@ -1057,9 +1064,6 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
 
-  // uint8 + squared L2 with rows of up to 128 bytes: integer contraction (bf_mfma_i8_kernel)
-  const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
-                      std::getenv("GGNN_BF_NO_I8") == nullptr;
   // float32 squared L2: rows are shifted by a column mean of the base (GGNN_BF_NO_CENTER=1: test
   // hook that leaves them unshifted so that offset data exercises the re-scan)
   const bool center = a.dtype == GGNN_F32 && a.measure == GGNN_EUCLIDEAN &&
@@ -1079,8 +1083,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_parts = pad4(parts);
   const size_t n_rescan = pad4(rescan_entries);
   const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
+  const size_t n_gthr = use_i8v2 ? pad4(a.Nq) : 0;  // per-query bound shared by the slices
   const size_t words =
-      n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan + n_qshift;
+      n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan + n_qshift + n_gthr;
   float* scratch = nullptr;
   GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), words * 4, stream));
   float* bnorm = scratch;
@@ -1094,7 +1099,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + n_parts);
   float* rescan_dists = reinterpret_cast<float*>(rescan_ids + n_rescan);
   float* q_shifted = rescan_dists + n_rescan;
+  uint32_t* gthr = reinterpret_cast<uint32_t*>(q_shifted + n_qshift);
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
+  if (use_i8v2)  // +inf
+    GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7f800000, a.Nq,
+                                     stream));
 
   if (center) {
     // at most ~32k evenly spaced rows: plenty for a shift, negligible next to the scan itself
@@ -1186,6 +1195,17 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                        dim3(norm_grid(a.Nq)), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.query), a.Nq, a.D,
                        static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr));
+  }
+  if (use_i8v2) {
+    m.gthr = std::getenv("GGNN_BF_I8_NOSHARE") ? nullptr : gthr;  // (A/B hook)
+    // GGNN_BF_I8_WARM=<rows>: seeding launch over the head of the base (tuning hook; off: a
+    // 40-workgroup launch costs more than the per-slice cold starts it saves)
+    const uint32_t warm = std::getenv("GGNN_BF_I8_WARM")
+                              ? static_cast<uint32_t>(std::atoi(std::getenv("GGNN_BF_I8_WARM")))
+                              : 0u;
+    launch_bf_i8v2(m, qblocks, slices, warm, stream);
+  }
+  else if (use_i8) {
     const size_t lds8 = 2 * kBfI8Tiles * kBfTileRows * kBfI8RowStride +
                         2 * kBfQueriesPerBlock * KP * sizeof(float);
     const uint32_t nm = (a.D + 31) / 32;

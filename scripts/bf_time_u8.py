@@ -1,19 +1,23 @@
-"""bf_query timing for uint8 rows (10k x 1M x 128, k=10)"""
+"""bf_query timing for uint8 rows (10k x 1M x 128, k=10); GGNN_BF_I8_V1=1 times the LDS-list kernel"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ggnn_amd import ops
 from bench import synthetic
 dev = torch.device("cuda", 0)
-base = synthetic("lowrank16", 1_000_000, 128, 1234, dev).to(torch.uint8)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+base = synthetic("lowrank16", n, 128, 1234, dev).to(torch.uint8)
 query = synthetic("lowrank16", 10_000, 128, 4321, dev).to(torch.uint8)
 for _ in range(2):
-    ids, d = ops.bf_query(base, query, 10)
+    ids, d = ops.bf_query(base, query, k)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5):
-    ids, d = ops.bf_query(base, query, 10)
+    ids, d = ops.bf_query(base, query, k)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print(f"bf_query u8 D=128: {ms:.2f} ms  {2*1e4*1e6*128/ms/1e9:.1f} Top/s")
+tag = "v1 (LDS lists)" if os.environ.get("GGNN_BF_I8_V1") else "v2 (register sets)"
+print(f"bf_query u8 {n}x128 k={k} {tag}: {ms:.2f} ms  {2*1e4*n*128/ms/1e9:.1f} Top/s "
+      f"checksum {int(ids.sum())} {float(d.sum())}")

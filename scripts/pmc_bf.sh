@@ -19,8 +19,8 @@ dur = collections.defaultdict(list)
 for f in glob.glob("$R/gpurun_out/pmc_bf_$tag/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "bf_mfma" in k:
-            k = k.split("(")[0]
+        if "bf_mfma" in k or "bf_i8v2" in k:
+            k = k.split("(")[0] + " grid=" + row.get("Grid_Size", "?")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             if "Start_Timestamp" in row:
                 dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9)

@@ -196,3 +196,34 @@ def test_bf_mfma_odd_sizes(ops, orc, N, Nq, K, D):
     s_ids, s_dists = scan_answer(ops, b, qq, K, 0)
     assert torch.equal(ids, s_ids) and torch.equal(dists, s_dists)
     check_against_float64(base, q, ids.cpu().numpy(), K, 0)
+
+
+@pytest.mark.parametrize("N,D,Nq,K", [(50_000, 128, 700, 10), (33_333, 128, 257, 3), (20_001, 96, 300, 16),
+                                      (9_000, 64, 513, 10), (4_100, 32, 256, 4), (70_000, 128, 1000, 1)])
+def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
+    """bf_i8v2_kernel (uint8, squared L2, K <= 16: per-query sets in registers, thresholds folded
+    into the accumulators and shared between the slices through atomics): results must be the
+    oracle's bit for bit -- with heavy ties (duplicated rows, extreme bytes), ragged sizes, many
+    slices, with and without the seeding launch, and equal to the LDS-list kernel it replaces."""
+    from ggnn_amd import ops
+    rng = np.random.default_rng(N + D + K)
+    base = rng.integers(0, 256, (N, D)).astype(np.uint8)
+    base[::97] = 255
+    base[5::101] = 0
+    base[N // 2:N // 2 + 400] = base[:400]          # ties across slices: lower index first
+    base[N - 300:] = base[100:400]                  # ... and at the very end of the base
+    q = rng.integers(0, 256, (Nq, D)).astype(np.uint8)
+    q[3] = 0
+    q[4] = 255
+    q[5:205] = base[100:300]                        # exact hits with three copies each
+    o_ids, o_d = orc.bf_query(base, q, K)
+    d_base, d_q = torch.from_numpy(base).cuda(), torch.from_numpy(q).cuda()
+    for env in ({}, {"GGNN_BF_SLICES": "7"}, {"GGNN_BF_SLICES": "23", "GGNN_BF_I8_WARM": "0"},
+                {"GGNN_BF_SLICES": "1"}, {"GGNN_BF_I8_V1": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        ids, d = ops.bf_query(d_base, d_q, K)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.array_equal(ids.cpu().numpy(), o_ids), env
+        assert np.array_equal(d.cpu().numpy(), o_d), env
