@@ -982,7 +982,11 @@ __global__ void __launch_bounds__(kWave) bf_rerank_kernel(const BfRerankArgs a)
   bool ok;
   if (MODE == kL2) {
     const float norms = a.qnorm[n] + __uint_as_float(*a.bnorm_max);
-    const float E = 1.01f * (2.f * Df + 8.f) * u * norms + 4.f * u * w;
+    // (+ an absolute term: products and partial sums in the denormal range -- coordinates around
+    // 1e-19 and below -- are rounded to a multiple of 2^-149, or flushed, an error the relative
+    // model does not see; (2D+8) 2^-125 covers D such roundings of either kind many times over)
+    const float E =
+        1.01f * (2.f * Df + 8.f) * u * norms + 4.f * u * w + (2.f * Df + 8.f) * 2.3509887e-38f;
     ok = (w - E) * (1.f - 1.01f * (Df + 3.f) * u) > d_k;
   }
   else {
@@ -1008,23 +1012,44 @@ bool bf_mfma_supported(const BfLaunch& a)
   return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
-// freed blocks stay in the device's pool instead of going back to the driver at the next
-// synchronisation: the per-call scratch of bf_query then costs no allocation after the first call
-static void keep_pool_memory(hipStream_t)
+// Per-call scratch comes from a PRIVATE stream-ordered pool per device (not the device's default
+// pool, whose settings belong to the rest of the process): freed blocks stay in it up to a
+// bounded amount, so repeated bf_query calls cost no allocation, and nothing else in the process
+// is affected.  GGNN_BF_POOL_KEEP_MB sets the amount kept (default 1024).
+static hipMemPool_t scratch_pool()
 {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-    return;
-  static bool done[64] = {};
-  if (done[dev])
-    return;
-  hipMemPool_t pool = nullptr;
-  if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-    uint64_t keep = ~0ull;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    return nullptr;
+  static hipMemPool_t pools[64] = {};
+  static bool tried[64] = {};
+  if (!tried[dev]) {
+    tried[dev] = true;
+    hipMemPoolProps props{};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+      uint64_t keep = 1024ull << 20;
+      if (const char* e = std::getenv("GGNN_BF_POOL_KEEP_MB"))
+        keep = static_cast<uint64_t>(std::max(0, std::atoi(e))) << 20;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      pools[dev] = pool;
+    }
+    (void)hipGetLastError();
   }
-  (void)hipGetLastError();
-  done[dev] = true;
+  return pools[dev];
+}
+static void* scratch_alloc(size_t bytes, hipStream_t stream)
+{
+  void* p = nullptr;
+  if (hipMemPool_t pool = scratch_pool())
+    GGNN_HIP_CHECK(hipMallocFromPoolAsync(&p, bytes, pool, stream));
+  else
+    GGNN_HIP_CHECK(hipMallocAsync(&p, bytes, stream));
+  return p;
 }
 
 size_t bf_rescan_tmp_entries(const BfLaunch& a, uint32_t* slices_out);
@@ -1035,7 +1060,6 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
 {
   check_vector_layout(a.base, a.D, a.dtype);
   check_vector_layout(a.query, a.D, a.dtype);
-  keep_pool_memory(stream);
   // a few more candidates than K per slice: makes the certificate (top of this file) succeed for
   // all but near-degenerate queries; correctness does not depend on the value
   // uint8 + squared L2 with rows of up to 128 bytes: integer contraction on the i8 matrix path;
@@ -1086,8 +1110,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_gthr = use_i8v2 ? pad4(a.Nq) : 0;  // per-query bound shared by the slices
   const size_t words =
       n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan + n_qshift + n_gthr;
-  float* scratch = nullptr;
-  GGNN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), words * 4, stream));
+  float* scratch = static_cast<float*>(scratch_alloc(words * 4, stream));
   float* bnorm = scratch;
   float* qnorm = bnorm + a.N_base;
   float* mean = scratch + n_norms;

@@ -227,3 +227,23 @@ def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
             monkeypatch.delenv(k_)
         assert np.array_equal(ids.cpu().numpy(), o_ids), env
         assert np.array_equal(d.cpu().numpy(), o_d), env
+
+
+@pytest.mark.parametrize("scale", [1e-19, 3e-21, 1e-23])
+def test_tiny_magnitudes_stay_exact(ops, scale):
+    """coordinates so small that squares and products are denormal (or flush to
+    zero).  The certificate's rounding model is relative; the absolute error of the denormal
+    range is covered by an explicit term, so such queries are either still certified correctly
+    or re-scanned -- the answer must equal the scan kernel's in every case."""
+    N, D, Nq, K = 20_000, 128, 300, 10
+    base = (_clustered(N, D, 41).astype(np.float64) * scale).astype(np.float32)
+    q = (_clustered(Nq, D, 42).astype(np.float64) * scale).astype(np.float32)
+    b, qq = dev(base), dev(q)
+    ids, d = ops.bf_query(b, qq, K, 0)
+    s_ids, s_d = scan_answer(ops, b, qq, K, 0)
+    assert torch.equal(d, s_d)
+    # distances that underflow to equal values may order tied rows either way: compare as sets
+    # wherever the distances at the boundary tie, exactly otherwise
+    same = (ids == s_ids).all(1)
+    for n in torch.nonzero(~same).flatten().tolist():
+        assert set(ids[n].tolist()) == set(s_ids[n].tolist()) or float(d[n, -1]) == float(d[n, 0]), n
