@@ -138,8 +138,8 @@ if c:
                        "is higher"},
               open(f"{out_dir}/{tag}_pmc_mfma_bf_query.json", "w"), indent=1)
 
-# other bf shapes (scripts/pmc_bf.sh summaries), if collected in this round
-for shape in ("d960", "d256", "u8"):
+# other bf shapes (scripts/pmc_bf.sh summaries), if collected in this round (headline tag only)
+for shape in (() if extra else ("d960", "d256", "u8")):
     p = f"gpurun_out/pmc_bf_{shape}/summary.json"
     if os.path.exists(p):
         doc = json.load(open(p))
@@ -147,6 +147,9 @@ for shape in ("d960", "d256", "u8"):
             d = v.get("kernel_duration_s_under_profiling")
             if d and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
                 v["mfma_busy_fraction_at_2.4GHz"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * 2.4e9 * d)
+                if "SQ_INSTS_MFMA" in v and v["SQ_INSTS_MFMA"]:
+                    v["valu_per_mfma"] = v.get("SQ_INSTS_VALU", 0.0) / v["SQ_INSTS_MFMA"]
+                    v["salu_per_mfma"] = v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_MFMA"]
         json.dump({"command": f"scripts/pmc_bf.sh {shape} ... (rocprofv3 --pmc, three passes over "
                               "scripts/bf_time*.py: 10 000 queries x 1 000 000 rows, k=10)",
                    "kernels": doc}, open(f"{out_dir}/{tag}_pmc_bf_{shape}.json", "w"), indent=1)
