@@ -135,6 +135,12 @@ def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the visited ring"
     if iters in (500, 512):
         assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
+    # 1000..2048 iterations: rings of 992 / 2016 keys, searched by the ring scan (a hashed set with
+    # four / eight bucket registers was exact too but slower: its LDS cost occupancy)
+    if (tau, iters) == (4.0, 1000):
+        assert int(o_np.max()) > 900, "the case is meant to fill the 992-entry ring"
+    if (tau, iters) == (5.0, 2048):
+        assert int(o_np.max()) > 1500, "the case is meant to go deep into the 2016-entry ring"
 
 
 # The visited ring is mirrored in a hash set (traversal.hpp, SortedList<R, HB>): buckets of 8 keys,
@@ -144,7 +150,9 @@ def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
 # are removed from buckets AND stash when the ring wraps).  Results and counters must not change.
 @pytest.mark.parametrize("slots", [1, 2, 4])
 @pytest.mark.parametrize("K,tau,iters", [(10, 0.64, 200), (10, 2.5, 250), (24, 3.0, 255),
-                                         (10, 0.64, 400), (10, 3.0, 512), (40, 3.0, 500)])
+                                         (10, 0.64, 400), (10, 3.0, 512), (40, 3.0, 500),
+                                         (10, 4.0, 1000), (10, 0.8, 1024), (10, 5.0, 2048),
+                                         (10, 1.0, 1500)])
 def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, iters, monkeypatch):
     g = small_graph
     q = make_int_data(96, g["D"], 4322)
@@ -165,6 +173,12 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the 192-entry ring"
     if iters in (500, 512):
         assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
+    # 1000..2048 iterations: rings of 992 / 2016 keys, searched by the ring scan (a hashed set with
+    # four / eight bucket registers was exact too but slower: its LDS cost occupancy)
+    if (tau, iters) == (4.0, 1000):
+        assert int(o_np.max()) > 900, "the case is meant to fill the 992-entry ring"
+    if (tau, iters) == (5.0, 2048):
+        assert int(o_np.max()) > 1500, "the case is meant to go deep into the 2016-entry ring"
 
 
 @pytest.mark.parametrize("slots", [1, 4])
