@@ -1087,10 +1087,14 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        # rank 0 measures the one-GPU point and the one-handle form while the others wait at a
+        # barrier: minutes, not seconds
+        patience = datetime.timedelta(minutes=45)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=patience)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=patience)
 
     import ggnn_amd as ggnn
     if world > 1:
