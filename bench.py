@@ -614,7 +614,8 @@ def run_single(args, device, ggnn):
     # the algorithmic bytes of THIS kernel are counted from its own row counters.
     fixed = nq * d * esz + cnt["n_pop"] * args.k_build * 4 + nq * (32 * 4 + 8 + k * 8)
     ref_bytes = fixed + cnt["n_dist"] * d * esz
-    code_dim = (d + 15) // 16 * 16
+    # prescreen_code_dim(D), common.hpp: power of two up to 64, then multiples of 64 bytes
+    code_dim = max(16, 1 << (d - 1).bit_length()) if d <= 64 else (d + 63) // 64 * 64
     prescreened = rows["code_rows"] > 0
     alg_bytes = fixed + rows["float_rows"] * d * esz + rows["code_rows"] * code_dim
     if prescreened:

@@ -118,7 +118,21 @@ void launch_query(const QueryLaunch& a, hipStream_t stream);
 // [N x Dc], Dc = D rounded up to 16; params [prescreen_param_floats(D)] floats; scratch
 // [prescreen_scratch_floats(N, D, measure)] floats.
 constexpr int kPsHeaderFloats = 8;
-inline uint32_t prescreen_code_dim(uint32_t D) { return (D + 15u) / 16u * 16u; }
+// Code-row length: rows must not straddle more memory lines than their length needs -- a
+// 96-byte code row at a 96-byte pitch touches 2.5 64-byte granules on average instead of 2 and a
+// 128-byte line boundary three times in four (profiles/r03_d96: 1.40x the algorithmic bytes on the
+// fabric).  Up to 64 dimensions the pitch is a power of two (several rows per line, none split),
+// above that a multiple of 64 bytes; padding codes are zero on both sides of every difference.
+inline uint32_t prescreen_code_dim(uint32_t D)
+{
+  if (D <= 64) {
+    uint32_t p = 16;
+    while (p < D)
+      p <<= 1;
+    return p;
+  }
+  return (D + 63u) / 64u * 64u;
+}
 size_t prescreen_param_floats(uint32_t D);
 size_t prescreen_scratch_floats(uint32_t N, uint32_t D, ggnn_measure measure);
 void launch_prescreen_encode(const float* base, uint32_t N, uint32_t D, ggnn_measure measure,

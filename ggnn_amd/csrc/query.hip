@@ -298,8 +298,8 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.vis_slots = vis_slots_from_env();
   const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
-    GGNN_REQUIRE(a.ps_Dc % 16 == 0 && a.ps_Dc >= a.D && a.ps_Dc < a.D + 16,
-                 GGNN_INVALID_ARGUMENT, "pre-screen code rows must be D rounded up to 16");
+    GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(a.D), GGNN_INVALID_ARGUMENT,
+                 "pre-screen code rows must have prescreen_code_dim(D) bytes");
     GGNN_REQUIRE((reinterpret_cast<uintptr_t>(a.ps_codes) & 15u) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.ps_params) & 15u) == 0,
                  GGNN_INVALID_ARGUMENT, "pre-screen buffers must be 16-byte aligned");

@@ -163,7 +163,7 @@ const char* ggnn_last_exchange(const ggnn_t* h);
 ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned);
 ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
 /* rows the last ggnn_query read for those evaluations (needs collect_counters): float rows
- * (4*D bytes each) and, with the pre-screen, 8-bit code rows (D rounded up to 16 bytes each). */
+ * (4*D bytes each) and, with the pre-screen, 8-bit code rows (prescreen_code_dim(D) bytes each: a power of two up to 64, multiples of 64 above). */
 ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows);
 /* Exact pre-screen of the float32 query and merge kernels (no reference counterpart; results
  * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
@@ -219,7 +219,8 @@ ggnn_status ggnn_op_query(const void* base, ggnn_dtype dtype, uint32_t N_base, u
  * bound (||q^ - x^|| - e_q - e_max)^2 already reaches the criteria is dropped without reading
  * its float row -- exactly the candidates the reference evaluates and then discards -- so ids,
  * distances and counters do not change.  The copy is specific to the measure it was made for.
- * code_dim = D rounded up to 16; codes [N_base x code_dim] bytes; params [param_floats] floats
+ * code_dim = prescreen_code_dim(D) (a power of two up to 64, multiples of 64 above: rows do not
+ * straddle more memory lines than their length needs); codes [N_base x code_dim] bytes; params [param_floats] floats
  * ([0] s, [1] 1/s, [2] e_max, [3] ||o||, [4] usable (0 when the data holds non-finite values),
  * [5..6] internal, [7] measure, [8..] o_d); scratch [scratch_floats] floats.  D must be a
  * multiple of 4. */

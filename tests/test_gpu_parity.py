@@ -681,7 +681,10 @@ def _clustered(N, D, seed, offset=0.0, scale=1.0):
 
 def test_prescreen_sizes_and_lossless_integers(ops):
     base = dev(make_int_data(3000, 128, 5))
-    assert ops.prescreen_sizes(3000, 128)[0] == 128 and ops.prescreen_sizes(3000, 100)[0] == 112
+    # code rows never straddle more lines than they need: powers of two up to 64, then 64-byte steps
+    assert ops.prescreen_sizes(3000, 128)[0] == 128 and ops.prescreen_sizes(3000, 100)[0] == 128
+    assert ops.prescreen_sizes(3000, 96)[0] == 128 and ops.prescreen_sizes(3000, 64)[0] == 64
+    assert ops.prescreen_sizes(3000, 200)[0] == 256 and ops.prescreen_sizes(3000, 960)[0] == 960
     codes, params = ops.prescreen_encode(base)
     p = params.cpu().numpy()
     assert p[0] == 1.0 and p[1] == 1.0 and p[2] == 0.0 and p[4] == 1.0
