@@ -741,20 +741,23 @@ def run_single(args, device, ggnn):
     print(json.dumps(out), flush=True)
 
 
-def sharded_case(args, device, world, rank, spg):
+def sharded_case(args, device, world, rank, spg, cpu_group):
     """One base of TOTAL_SHARDS x args.n_base points partitioned over the ranks (one process per
     GPU): blocking 10k-query steps (the contract's timed region), a saturating 100k-query batch
     and two batches in flight.  Times are the MAX over ranks."""
     from ggnn_amd.distributed import ShardedGGNN
-    red_dev = device if args.backend == "nccl" else "cpu"
 
+    # coordination goes through a host-side (gloo) group: a rank that waits in an RCCL barrier
+    # spins in a kernel on its GPU, which would disturb whatever still runs there (rank 0's
+    # reference point, the one-handle child that drives all GPUs)
     def barrier():
-        dist.barrier()
+        torch.cuda.synchronize()
+        dist.barrier(group=cpu_group)
         torch.cuda.synchronize()
 
     def max_over_ranks(*vals):
-        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cpu_group)
         return [float(v) for v in t.tolist()]
 
     base = big_base(args, spg * args.n_base, rank * spg, device)
@@ -939,9 +942,12 @@ def run_sharded(args, device, ggnn, world, rank):
         raise SystemExit(f"--gpus must divide {TOTAL_SHARDS}")
     spg = TOTAL_SHARDS // world
 
+    import datetime
+    cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=45))
+
     def barrier():
-        dist.barrier()
         torch.cuda.synchronize()
+        dist.barrier(group=cpu_group)
 
     ref_steps = max(5, args.steps // 2)
     main_base = args.n_base
@@ -949,7 +955,7 @@ def run_sharded(args, device, ggnn, world, rank):
     for n_base in [main_base] + ([args.secondary_n_base] if args.secondary_n_base and
                                  args.secondary_n_base != main_base else []):
         args.n_base = n_base
-        case = sharded_case(args, device, world, rank, spg)
+        case = sharded_case(args, device, world, rank, spg, cpu_group)
         # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
         one = None
         if rank == 0 and not args.no_scaling_reference:
