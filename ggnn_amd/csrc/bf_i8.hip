@@ -48,10 +48,14 @@ constexpr int kTeInf = 1 << 30;
 #ifdef GGNN_I8_STATS
 // debug build (make TARGET=libggnn_dbg.so OBJDIR=build_dbg EXTRA=-DGGNN_I8_STATS): event counts of
 // the kernel below, read back with ggnn_debug_i8_stats()
-__device__ unsigned long long g_i8_stats[8];
+__device__ unsigned long long g_i8_stats[16];
 #define I8_STAT(i, n) do { if (lane == 0) atomicAdd(&g_i8_stats[i], (unsigned long long)(n)); } while (0)
+#define I8_T0() const long long _t0 = clock64()
+#define I8_T1(i) I8_STAT(i, clock64() - _t0)
 #else
 #define I8_STAT(i, n) do { } while (0)
+#define I8_T0() do { } while (0)
+#define I8_T1(i) do { } while (0)
 #endif
 
 GGNN_DEV int i8v2_qrow(int r, int h)
@@ -136,6 +140,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   i32x16 cinit[2];
 
   auto refresh_offsets = [&]() {
+    I8_T0();
     const int c = qn_q - Te;
     I8_STAT(6, 1);
     hq_used = c >> 1;
@@ -150,12 +155,14 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       for (int r = 0; r < 16; ++r)
         cinit[s2][r] = -hq_w[s2 * 32 + i8v2_qrow(r, h)];
     __builtin_amdgcn_wave_barrier();
+    I8_T1(9);
   };
 
   // applies the pending candidates of all 64 queries in lockstep: one sorted insertion per
   // query and iteration, all in registers (two 64-bit compares and four selects per slot)
   auto flush = [&]() {
     I8_STAT(3, 1);
+    I8_T0();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int cnt = min(pc_w[lane], kI8v2Pend);
@@ -164,7 +171,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       I8_STAT(4, 1);
       const bool have = i < cnt;
       // (an absent record is "infinity": it changes nothing)
-      const int rd = have ? pd_w[i * 64 + lane] : 0x7fffffff;
+      const int rd = have ? qn_q - pd_w[i * 64 + lane] : 0x7fffffff;
       const int rid = have ? pi_w[i * 64 + lane] : 0x7fffffff;
       const unsigned long long rec =
           (static_cast<unsigned long long>(static_cast<unsigned>(rd)) << 32) | static_cast<unsigned>(rid);
@@ -193,6 +200,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       offsets_stale = true;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    I8_T1(8);
   };
 
   // threshold exchange with the other slices + accumulator offsets, every few stages
@@ -246,6 +254,9 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       bns[buf * SR + tid] = bn;
   };
 
+#ifdef GGNN_I8_STATS
+  const long long t_kernel0 = clock64();
+#endif
   const uint32_t nstages = (end > begin) ? (end - begin + SR - 1) / SR : 0;
   if (nstages) {
     stage_load(begin, sva, bna);
@@ -258,16 +269,15 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   stage_load(begin + SR, svb, bnb);
 
   // Hits of one tile-set, in the matrix layout: a lane whose accumulator r passed the test
-  // recomputes the exact integer distance (its offset is cinit[r]; norm and current threshold of
-  // the query come from LDS) and appends a survivor to the query's pending list, the slot taken
-  // with an LDS atomic.  Measured on the 1M x 128 base: 16 % of the tile-sets have hits, 6.7
+  // appends (2 q'.b' - |b'|^2, row index) to the pending list of query (r, h), the slot taken with
+  // an LDS atomic; the query's bookkeeping lane turns that into the distance (it knows |q'|^2)
+  // and decides in the batch update.  Measured on the 1M x 128 base: 16 % of the tile-sets have hits, 6.7
   // on average (a row that is close to one query of the batch is close to many), 87 % of them
   // survive.  A lane whose list is full remembers the register in `redo`; the caller applies the
   // pending candidates and runs the pass again for those.
-  // (Tried and dropped: appending every accumulator hit without the fresh-threshold check and
-  // issuing all atomics before the first slot is used -- one LDS round trip per tile-set instead
-  // of three per hit, but 4.8 instead of 3.7 ms: the stale hits fill the lists, and the slot array
-  // costs more VALU than the latency it hides.)
+  // (Tried and dropped: issuing all atomics of a tile-set before the first slot is used -- one LDS
+  // round trip instead of one per hit, but the slot array costs more VALU than the latency it
+  // hides: 4.8 instead of 3.6 ms.)
   auto scan_pass = [&](const i32x16& acc, const i32x16& off, const int s2, int bnv, int b0,
                        int id, unsigned& redo, const bool first) __attribute__((always_inline)) {
 #pragma unroll
@@ -279,11 +289,12 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       if (hit) {
         I8_STAT(1, 1);
         const int q = s2 * 32 + i8v2_qrow(r, h);
-        const int d = qn_w[q] + bnv - 2 * (acc[r] - off[r]);
-        if (d < te_w[q]) {
+        {
+          // (no fresh-threshold test here: it costs an LDS round trip in front of the atomic, and
+          // the offsets are at most a few tiles stale -- the batch update decides)
           const int slot = atomicAdd(pc_w + q, 1);
           if (slot < kI8v2Pend) {
-            pd_w[slot * 64 + q] = d;
+            pd_w[slot * 64 + q] = 2 * (acc[r] - off[r]) - bnv;
             pi_w[slot * 64 + q] = id;
             I8_STAT(2, 1);
           }
@@ -295,6 +306,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   };
   auto tile_set = [&](const i32x16& acc, const i32x16& off, const int s2, int bnv, int b0, int id)
                       __attribute__((always_inline)) {
+    I8_T0();
     unsigned redo = 0;
     scan_pass(acc, off, s2, bnv, b0, id, redo, true);
     while (__any(redo != 0u)) {
@@ -303,6 +315,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
     }
     if (__any(pc_w[lane] >= kI8v2Pend / 2))
       flush();
+    I8_T1(10);
   };
 
   auto stage_body = [&](const uint32_t st, uint4 (&v_cur)[PPT], int& bn_cur,
@@ -314,8 +327,11 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
     // set `cur` held stage st (in LDS since the end of the previous stage): reuse it for st + 2
     stage_load(row0 + 2 * SR, v_cur, bn_cur);
 #if !defined(GGNN_I8_EXP) || GGNN_I8_EXP != 2   // (2: timing experiment without the exchange)
-    if (st && st % kI8v2Refresh == 0)
+    if (st && st % kI8v2Refresh == 0) {
+      I8_T0();
       refresh();
+      I8_T1(12);
+    }
 #endif
     // the B operands of tile t + 1 are requested while the MFMAs of tile t run (the hit handling
     // in between touches LDS, so the compiler keeps the reads behind it on its own)
@@ -329,6 +345,9 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
         break;  // uniform
       if (offsets_stale)
         refresh_offsets();
+#ifdef GGNN_I8_STATS
+      const long long t_tile0 = clock64();
+#endif
       i32x16 acc[2];
       acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[0][0], bq[t & 1][0], cinit[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[1][0], bq[t & 1][0], cinit[1], 0, 0, 0);
@@ -352,6 +371,11 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
         mx1 = max(max(mx1, acc[1][r]), acc[1][(r + 1) & 15]);
       }
       I8_STAT(5, 2);
+#ifdef GGNN_I8_STATS
+      {
+        I8_STAT(13, clock64() - t_tile0);
+      }
+#endif
 #if defined(GGNN_I8_EXP) && GGNN_I8_EXP == 1   // timing experiment: no hit handling at all
       if (mx0 == 0x7ffffff0 || mx1 == 0x7ffffff0)
         te_w[lane] = b0;
@@ -366,9 +390,19 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
         tile_set(acc[1], cinit[1], 1, bnv, b0, static_cast<int>(row0 + t * kBfTileRows) + j);
       }
     }
+#ifdef GGNN_I8_STATS
+    const long long t_end0 = clock64();
+#endif
     if (st + 1 < nstages)
       stage_store((st + 1) & 1, v_next, bn_next);
+#ifdef GGNN_I8_STATS
+    const long long t_end1 = clock64();
+#endif
     __syncthreads();
+#ifdef GGNN_I8_STATS
+    I8_STAT(14, t_end1 - t_end0);
+    I8_STAT(15, clock64() - t_end1);
+#endif
   };
   for (uint32_t st = 0; st < nstages; st += 2) {
     stage_body(st, sva, bna, svb, bnb);
@@ -376,6 +410,9 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       stage_body(st + 1, svb, bnb, sva, bna);
   }
 
+#ifdef GGNN_I8_STATS
+  I8_STAT(11, clock64() - t_kernel0);
+#endif
   flush();
   if (a.gthr && my_valid && sd[KPT - 1] < last_pub)
     atomicMin(a.gthr + my_q, __float_as_uint(static_cast<float>(sd[KPT - 1])));
@@ -396,7 +433,7 @@ extern "C" int ggnn_debug_i8_stats(unsigned long long* out, int reset)
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_i8_stats), sizeof(g_i8_stats)) != hipSuccess)
     return 1;
   if (reset) {
-    unsigned long long z[8] = {};
+    unsigned long long z[16] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stats), z, sizeof(z));
   }
   return 0;

@@ -10,13 +10,15 @@ from bench import synthetic
 dev = torch.device("cuda", 0)
 base = synthetic("lowrank16", 1_000_000, 128, 1234, dev).to(torch.uint8)
 query = synthetic("lowrank16", 10_000, 128, 4321, dev).to(torch.uint8)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 ops.bf_query(base, query, 10); torch.cuda.synchronize()
 lib().ggnn_debug_i8_stats(out, 1)
 ops.bf_query(base, query, 10); torch.cuda.synchronize()
 lib().ggnn_debug_i8_stats(out, 1)
-names = ["tile-sets entered", "filter hits", "appended", "flush calls", "flush iterations",
-         "tile-sets", "offset refreshes", "-"]
+names = ["tile-sets entered", "filter hits (lane 0)", "appended (lane 0)", "flush calls",
+         "flush iterations", "tile-sets", "offset refreshes", "-", "cycles in flush",
+         "cycles in refresh_offsets", "cycles in tile_set (incl. its flushes)", "cycles in main loop (per wave, summed)",
+         "cycles in refresh (exchange)", "cycles MFMA..max3..any per tile", "cycles stage_store (incl. wait for the loads)", "cycles in barrier"]
 ts = max(1, out[5])
 for n, v in zip(names, out):
     print(f"{n:20s} {v:12d}  per tile-set {v / ts:.4f}")
