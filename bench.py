@@ -787,7 +787,34 @@ def sharded_case(args, device, world, rank, spg, cpu_group):
         kernel_ms.append(eng.last_timing_ms()["query_ms"])
     barrier()
     elapsed, = max_over_ranks(time.perf_counter() - t0)
-    out = {"n_base_per_shard": args.n_base, "shards_per_gpu": spg,
+    # work counters of one pass (untimed) for the aggregate roofline figure: bytes the kernels
+    # of all ranks read by their own accounting / the slowest rank's kernel time / N x 8 TB/s
+    eng.set_collect_counters(True)
+    step()
+    cnt, rows = eng.last_query_counters(), eng.last_query_rows_read()
+    eng.set_collect_counters(False)
+    kms = float(np.mean(kernel_ms))
+    tot = torch.tensor([cnt["n_dist"], cnt["n_pop"], rows["float_rows"], rows["code_rows"]],
+                       dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=cpu_group)
+    kmax, = max_over_ranks(kms)
+    n_dist, n_pop, float_rows, code_rows = (float(v) for v in tot.tolist())
+    d_, nq_ = args.dim, args.n_query
+    code_dim = max(16, 1 << (d_ - 1).bit_length()) if d_ <= 64 else (d_ + 63) // 64 * 64
+    shards_total = spg * world
+    alg_bytes = (float_rows * d_ * 4 + code_rows * code_dim + n_pop * args.k_build * 4 +
+                 shards_total * nq_ * (d_ * 4 + 32 * 4 + 8 + args.k * 8 +
+                                       ((code_dim + 8) * 4 if code_rows else 0)))
+    roofline = {"bound": "hbm", "achieved": alg_bytes / (kmax * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": alg_bytes / (kmax * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                "bytes_per_step_all_ranks": alg_bytes, "kernel_ms_slowest_rank": kmax,
+                "n_dist_per_query_all_shards": n_dist / nq_,
+                "definition": "algorithmic bytes of the query kernels of ALL ranks per step (their "
+                              "own row counters, as in the N=1 line) / the slowest rank's summed "
+                              "kernel time (HIP events) / (N x 8 TB/s); the exchange and merge "
+                              "are in ms_per_step, not in this kernel figure"}
+    out = {"n_base_per_shard": args.n_base, "shards_per_gpu": spg, "roofline": roofline,
            "elapsed_s": elapsed, "ms_per_step": elapsed / args.steps * 1e3,
            "queries_per_s": args.n_query / (elapsed / args.steps),
            "recall_at_10": recall_at_k(ids, gt),
@@ -1012,7 +1039,7 @@ def run_sharded(args, device, ggnn, world, rank):
             "secondary_base": (None if len(cases) < 2 else dict(
                 cases[1], note=f"the same series on {TOTAL_SHARDS} x {cases[1]['n_base_per_shard']} "
                                "points (the round-1/2 default)")),
-            "roofline": None, "cpu_baseline": None,
+            "roofline": main.get("roofline"), "cpu_baseline": None,
             "note": "N=1 of this command is the BASELINE single-shard configuration (1M points); "
                     "the multi-GPU series keeps the BASE fixed (north star: 100M points) instead, "
                     "so compare with one_gpu_same_base -- all 8 shards resident on one MI355X, "

@@ -34,6 +34,9 @@ def test_bench_two_ranks_dry_run():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert "160000 points" in out["config"]["workload"]
     assert out["recall_at_10"] > 0.9
+    rl = out["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 16000.0 and 0 < rl["frac"] < 1
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
     one = out["one_gpu_same_base"]
     assert one["queries_per_s"] > 0 and "saturated_batch" in one and "pipelined_batches" in one
     for key in ("speedup_vs_one_gpu_same_base", "saturated_speedup_vs_one_gpu_same_base",
