@@ -564,6 +564,15 @@ struct LdsList {
   GGNN_DEV int key_at(int i) const { return key[i]; }
   GGNN_DEV float criteria() const { return dist[BEST - 1] + xi; }
 
+  // simple_knn_cache.cuh:126-213, one chunk of 64 logical entries at a time from the top.  The
+  // reference separates "shift", "read the left neighbour", "insert" by barriers (four per chunk);
+  // here a chunk is ONE read phase (entry, and the left neighbour's distance) and ONE write phase:
+  //  * the left neighbour's distance is read before anything in or below this chunk is written,
+  //    and that is the value the reference's later read decides on as well: a slot left of an
+  //    insertion point is not active, so nothing shifts into it;
+  //  * an inserting lane and the lane left of it never write the same slot for the same reason;
+  //  * writes of a chunk touch the chunk itself and the first slot of the chunk above, which was
+  //    read an iteration earlier.
   GGNN_DEV void push(int k, float d)
   {
     const int lane = threadIdx.x;
@@ -575,52 +584,45 @@ struct LdsList {
       return;
     const int head = pq_head;
     const int head_in = head - BEST;
-    int r_key = kEmptyKey, idx = 0;
-    float r_dist = 0.f;
-    bool active = false;
-    int block_start = (SORTED + kWave - 1) / kWave * kWave;
-    for (;;) {
-      // shift (all lanes), then neighbour reads (all lanes), then inserts (all lanes)
-      if (active && r_key != kEmptyKey) {
-        const int idx_next = (idx + 1 == SORTED) ? BEST : idx + 1;
-        if (idx_next != BEST && idx_next != head) {  // Q1
-          key[idx_next] = r_key;
-          dist[idx_next] = r_dist;
-        }
-      }
-      __syncthreads();
-      bool ins = false;
-      if (active) {
-        const bool has_prev = idx != 0 && idx != head;
-        const int idx_prev = idx != BEST ? idx - 1 : SORTED - 1;
-        ins = !has_prev || dist[idx_prev] < d;
-      }
-      __syncthreads();
-      if (ins) {
-        key[idx] = k;
-        dist[idx] = d;
-      }
-      __syncthreads();
-      if (!block_start)
-        break;
-      block_start -= kWave;
+    for (int block_start = (SORTED + kWave - 1) / kWave * kWave - kWave; block_start >= 0;
+         block_start -= kWave) {
       const int li = block_start + lane;
-      active = li < SORTED;
+      bool active = li < SORTED;
+      int idx = 0, r_key = kEmptyKey;
+      float r_dist = 0.f, p_dist = -inf_f();
       if (active) {
         idx = li;
         if (li >= BEST)
           idx = (li + head_in < SORTED) ? li + head_in : li + head_in - SORTED + BEST;
         r_key = key[idx];
         r_dist = dist[idx];
+        const bool has_prev = idx != 0 && idx != head;
+        const int idx_prev = idx != BEST ? idx - 1 : SORTED - 1;
+        if (has_prev)
+          p_dist = dist[idx_prev];
         active = r_dist >= d;  // Q2
       }
+      __syncthreads();  // every read of the chunk before its writes
+      if (active) {
+        if (p_dist < d) {
+          key[idx] = k;
+          dist[idx] = d;
+        }
+        if (r_key != kEmptyKey) {
+          const int idx_next = (idx + 1 == SORTED) ? BEST : idx + 1;
+          if (idx_next != BEST && idx_next != head) {  // Q1
+            key[idx_next] = r_key;
+            dist[idx_next] = r_dist;
+          }
+        }
+      }
       // a chunk of the best list in which nothing shifts: neither does anything below it (the
-      // list is sorted), and the insertion point was settled by the chunk above (it reads its
-      // neighbour's distance itself) -- on average this halves the walk
+      // list is sorted) -- on average this halves the walk
       if (block_start + kWave <= BEST && !__any(active))
         break;
       __syncthreads();
     }
+    __syncthreads();
   }
 
   GGNN_DEV int pop(float crit)
