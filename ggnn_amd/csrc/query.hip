@@ -210,6 +210,9 @@ void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_
 }
 
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
+static void launch_query_lds(const QueryArgs& args, uint32_t sorted, hipStream_t stream);
+
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(args.cache);
@@ -237,7 +240,29 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   else if (sorted <= 512)  // KQuery <= 495: eight list registers per lane
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 8, MODE, PSC>), grid_for(args.Nq), dim3(kWave), lds,
                        stream, args);
-  else {
+  else if constexpr (!PSC::enabled) {
+    // KQuery <= 1007 / 2031: 16 / 32 list registers per lane.  A push is then 16 / 32 lock-step
+    // register steps (~12 instructions each) instead of a walk through LDS with a round trip or
+    // two per 64 entries -- with K this large nearly every evaluated candidate is pushed, so
+    // the pushes ARE the search (K = 1000 / 4 000 iterations: 24 pushes per pop).  Launched
+    // without the pre-screen (launch_query_cfg): a loose criteria rejects nothing.
+    if (sorted <= 1024)
+      hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 16, MODE, PSC>), grid_for(args.Nq), dim3(kWave),
+                         lds, stream, args);
+    else if (sorted <= 2048)
+      hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 32, MODE, PSC>), grid_for(args.Nq), dim3(kWave),
+                         lds, stream, args);
+    else
+      launch_query_lds<BaseT, LPR, NCH, MODE, PSC>(args, sorted, stream);
+  }
+  else
+    launch_query_lds<BaseT, LPR, NCH, MODE, PSC>(args, sorted, stream);
+}
+
+template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
+static void launch_query_lds(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
+{
+  {
     // SORTED > 512: sorted list in LDS (keys [cache] + dists [sorted] + candidate scratch)
     const size_t lds_big = (args.cache + sorted + WaveLds::extra_ints) * sizeof(int);
     GGNN_REQUIRE(lds_big <= 64 * 1024, GGNN_UNSUPPORTED, "cache too large for one workgroup");
@@ -251,7 +276,7 @@ static void launch_query_cfg(const QueryArgs& args, bool use_ps, ggnn_measure me
                              hipStream_t stream)
 {
   if constexpr (std::is_same<BaseT, float>::value) {
-    if (use_ps) {
+    if (use_ps && args.sorted <= 512) {
       if (measure == GGNN_EUCLIDEAN)
         launch_query_r<BaseT, LPR, NCH, kL2, typename PsFor<LPR, NCH, kL2>::type>(
             args, args.sorted, stream);

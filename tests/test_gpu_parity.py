@@ -632,14 +632,20 @@ def test_engine_pads_arbitrary_dimensions(orc, dtype, D):
     assert np.array_equal(ids.numpy(), o[0]) and np.array_equal(d.numpy(), o[1])
 
 
-@pytest.mark.parametrize("K,iters", [(240, 400), (300, 512), (1000, 1024)])
-def test_query_lds_list_for_very_large_k(ops, orc, small_graph, K, iters):
-    """KQuery > 239: the sorted list lives in LDS (wave64 port of the literal shift-insert)."""
+@pytest.mark.parametrize("K,iters,ps", [(240, 400, False), (300, 512, False), (1000, 1024, False),
+                                        (600, 1000, True), (1007, 2000, False), (1500, 2048, False),
+                                        (2031, 2048, True), (2040, 2048, False), (2047, 512, False)])
+def test_query_lds_list_for_very_large_k(ops, orc, small_graph, K, iters, ps):
+    """KQuery > 239: 8 / 16 / 32 list registers per lane up to KQuery 495 / 1007 / 2031 (the
+    pre-screen is not used there), above that the sorted list lives in LDS (wave64 port of the
+    literal shift-insert)."""
     g = small_graph
     q = make_int_data(12, g["D"], 97)
     graph0 = g["graph"][:g["N"]]
-    ids, d, nd, npop = ops.query(dev(g["base"]), dev(q), dev(graph0), dev(start_points(g)),
-                                 dev(g["stats"]), K, 0.8, iters, counters=True)
+    b = dev(g["base"])
+    ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start_points(g)),
+                                 dev(g["stats"]), K, 0.8, iters, counters=True,
+                                 prescreen=ops.prescreen_encode(b) if ps else None)
     o_ids, o_d, o_nd, o_np = orc.query(g["base"], q, graph0, start_points(g), g["stats"], K, 0.8,
                                        iters, counters=True)
     assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
