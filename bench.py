@@ -327,7 +327,9 @@ def bf_block(args, bf_ms, rescanned):
     """exact brute force (the recall ground truth) against the matrix-core peak of its dtype"""
     ops_ = 2.0 * args.n_query * args.n_base * args.dim
     if args.dtype == "u8" and args.measure == "l2" and args.dim <= 128:
-        kernel, peak, unit = "bf_mfma_i8_kernel (v_mfma_i32_32x32x32_i8), exact integers", I8_MFMA_PEAK, "TOPS"
+        kernel = ("bf_i8v2_kernel (v_mfma_i32_32x32x32_i8, K-best sets in registers), exact integers"
+                  if args.k <= 16 else "bf_mfma_i8_kernel (v_mfma_i32_32x32x32_i8, LDS lists), exact integers")
+        peak, unit = I8_MFMA_PEAK, "TOPS"
     else:
         kernel, peak, unit = ("bf_mfma_kernel (v_mfma_f32_32x32x2_f32) + certified exact re-rank",
                               F32_MFMA_PEAK, "TFLOP/s")
