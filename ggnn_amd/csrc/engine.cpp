@@ -265,6 +265,9 @@ struct DeviceCtx {
     DeviceBuffer m_pack;   // merged results, [ids: Nq x K][dists: Nq x K] (this GPU's slice filled)
     PinnedBuffer h_pack;   // the merged slice on the host, [ids: count x K][dists: count x K]
     hipEvent_t done{nullptr};  // local search of this lane finished (copy exchange)
+    // (first GPU, copy exchange of asynchronous batches) the rows of every GPU have been copied
+    // out: their owners may overwrite them with the next batch of this lane
+    hipEvent_t consumed{nullptr};
   };
   ExchangeBufs xb[kShardStreams + 1];
   hipStream_t lane_stream(int lane) const
@@ -306,6 +309,8 @@ struct DeviceCtx {
       xb[i].h_pack = std::move(o.xb[i].h_pack);
       xb[i].done = o.xb[i].done;
       o.xb[i].done = nullptr;
+      xb[i].consumed = o.xb[i].consumed;
+      o.xb[i].consumed = nullptr;
     }
     d_base = o.d_base;
     first_shard = o.first_shard;
@@ -325,9 +330,12 @@ struct DeviceCtx {
           (void)hipEventDestroy(shard_done[i]);
           (void)hipStreamDestroy(shard_stream[i]);
         }
-      for (int i = 0; i <= kShardStreams; ++i)
+      for (int i = 0; i <= kShardStreams; ++i) {
         if (xb[i].done)
           (void)hipEventDestroy(xb[i].done);
+        if (xb[i].consumed)
+          (void)hipEventDestroy(xb[i].consumed);
+      }
       (void)hipStreamDestroy(stream);
     }
   }
@@ -1192,6 +1200,13 @@ struct ggnn_handle {
       GGNN_HIP_CHECK(hipMemcpyAsync(x.g_pack.as<int32_t>() + g * 2 * part,
                                     devs[g].xb[lane].r_pack.p, 2 * part * 4, hipMemcpyDefault, st));
     }
+    if (!blocking) {
+      // the other GPUs' next batch on this lane overwrites the rows just copied: they wait for
+      // this point (query_async), the copies run on THIS GPU's stream
+      if (!x.consumed)
+        GGNN_HIP_CHECK(hipEventCreateWithFlags(&x.consumed, hipEventDisableTiming));
+      GGNN_HIP_CHECK(hipEventRecord(x.consumed, st));
+    }
     int32_t* m_ids = x.m_pack.as<int32_t>();
     launch_merge_results_range(nq, k_query, static_cast<uint32_t>(G), static_cast<uint32_t>(row),
                                shards_per_gpu * cfg.N, x.g_pack.as<int32_t>(),
@@ -1277,6 +1292,11 @@ struct ggnn_handle {
         GGNN_HIP_CHECK(hipMemcpyAsync(x.q_stage.p, d_query, qbytes, hipMemcpyDefault, st));
         q_here = x.q_stage.p;
       }
+      // (copy exchange: the first GPU may still be copying this lane's previous rows)
+#ifndef GGNN_EXP_NO_CONSUMED_WAIT  // (test-the-test hook)
+      if (&ctx != &devs[0] && devs[0].xb[lane].consumed)
+        GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[0].xb[lane].consumed, 0));
+#endif
       DeviceCtx::grow(x.r_pack, 2 * part * 4);
       int32_t* r = x.r_pack.as<int32_t>();
       enqueue_local_search(ctx, lane, q_here, nq, k_query, tau_query, max_iterations, measure, r,

@@ -555,3 +555,30 @@ def test_query_async_ticket_keeps_inputs_alive():
     assert not eng._inflight
     for ids, d in outs:
         assert torch.equal(ids, ref[0]) and torch.equal(d, ref[1])
+
+
+def test_query_async_multi_gpu_many_batches_in_flight():
+    """Batches of one lane reuse that lane's buffers on every GPU context.  With the copy exchange
+    the FIRST GPU copies the other contexts' rows on its own stream, so their owners must not
+    start the lane's next local search before that copy has run (found by the full-size dry run
+    of bench.py --gpus 2: results of pipelined batches differed from the blocking calls)."""
+    import ggnn_amd as ggnn
+    from bench import synthetic
+    dev_ = torch.device("cuda", 0)
+    N, D, K = 400_000, 128, 10
+    base = synthetic("lowrank16", N, D, 11, dev_)
+    qa = synthetic("lowrank16", 6000, D, 12, dev_)
+    qb = synthetic("lowrank16", 6000, D, 13, dev_)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_gpus([0, 0])
+    eng.set_shard_size(100_000)
+    eng.build(24, 0.5, 1)
+    ra, rb = eng.query(qa, K, 0.9, 175), eng.query(qb, K, 0.9, 175)
+    for rounds in range(3):
+        tickets = [eng.query_async(qa if i % 2 == 0 else qb, K, 0.9, 175, slot=i % 2)
+                   for i in range(12)]
+        eng.synchronize()
+        for i, t in enumerate(tickets):
+            want = ra if i % 2 == 0 else rb
+            assert torch.equal(t.ids.cpu(), want[0]) and torch.equal(t.dists.cpu(), want[1]), (rounds, i)
