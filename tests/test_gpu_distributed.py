@@ -117,3 +117,45 @@ def test_bench_single_gpu_line_small():
     one = d["strong_scaling_one_gpu"]
     assert one["queries_per_s"] > 0 and "pipelined_batches" in one
     assert d["build"]["merge_kernel"]["prescreened"]["ms"] > 0
+
+
+def test_sharded_engine_over_rccl_one_rank_world():
+    """The process-per-GPU path with the backend the driver uses (`nccl` = RCCL): a one-rank world
+    on the one GPU of the test box -- `all_gather_into_tensor` of the packed CUDA candidates, the
+    device merge, blocking and pipelined queries -- against a plain single handle."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["GGNN_ROOT"])
+import ggnn_amd as ggnn
+from ggnn_amd.distributed import ShardedGGNN
+from bench import synthetic
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+base = synthetic("lowrank16", 60000, 64, 1, dev)
+q = synthetic("lowrank16", 500, 64, 2, dev)
+s = ShardedGGNN()
+s.set_base(base)
+s.set_shard_size(20000)           # three resident shards on the one rank
+s.build(24, 0.5, 1)
+ids, d = s.query(q, 10, 0.9, 200)
+gt, gd = s.bf_query(q, 10)
+t = s.query_async(q, 10, 0.9, 200, slot=1)
+ids2, d2 = s.finish(t)
+assert ids.is_cuda and tuple(ids.shape) == (500, 10)
+assert torch.equal(ids, ids2) and torch.equal(d, d2)
+ref = ggnn.GGNN(); ref.set_base_reference(base); ref.set_shard_size(20000)
+ref.set_return_results_on_gpu(True); ref.build(24, 0.5, 1)
+rg, rd = ref.bf_query(q, 10)
+assert torch.equal(gd, rd[:, :10]) and torch.equal(gt, rg[:, :10])
+rec = (ids.unsqueeze(2) == gt.unsqueeze(1)).any(2).float().mean().item()
+assert rec > 0.95, rec
+dist.destroy_process_group()
+print("OK", rec)
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 300) + 101),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GGNN_ROOT=ROOT,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
