@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(256) shift_rows_kernel(const float* in, uint64
 
 inline uint32_t norm_grid(uint32_t rows)
 {
-  return std::max(1u, std::min((rows + 15u) / 16u, 8192u));
+  // (2048 workgroups: enough to fill the chip with four rows in flight per lane group, and a
+  // quarter of the per-wave atomics on the one norm-maximum word, which is what a launch of 8192
+  // spent most of its 0.37 ms on)
+  return std::max(1u, std::min((rows + 15u) / 16u, 2048u));
 }
 
 // Column means of (a sample of) the base: partial[p][c] = sum over rows p, p+P, ... of the
@@ -1213,7 +1216,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
                        dim3(norm_grid(a.N_base)), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.base), a.N_base, a.D,
-                       static_cast<const float*>(nullptr), bnorm, flags);
+                       static_cast<const float*>(nullptr), bnorm,
+                       static_cast<uint32_t*>(nullptr));  // (exact integers: no certificate, no maximum)
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
                        dim3(norm_grid(a.Nq)), dim3(256), 0, stream,
                        static_cast<const uint8_t*>(a.query), a.Nq, a.D,
