@@ -978,11 +978,25 @@ def run_sharded(args, device, ggnn, world, rank):
         torch.cuda.synchronize()
         dist.barrier(group=cpu_group)
 
+    # optional parts are dropped (and say so) when the run is already long: the line matters more
+    t_start = time.perf_counter()
+
+    def still_time(limit_s):
+        """rank 0 decides, everyone follows"""
+        ok = torch.tensor([1 if time.perf_counter() - t_start < limit_s else 0], dtype=torch.int32)
+        dist.broadcast(ok, src=0, group=cpu_group)
+        return bool(ok.item())
+
     ref_steps = max(5, args.steps // 2)
     main_base = args.n_base
     cases = []
+    skipped = []
     for n_base in [main_base] + ([args.secondary_n_base] if args.secondary_n_base and
                                  args.secondary_n_base != main_base else []):
+        if n_base != main_base and not still_time(args.optional_budget_s + 90):
+            skipped.append(f"secondary base of 8 x {n_base}: run already longer than "
+                           f"{args.optional_budget_s + 90:.0f} s")
+            break
         args.n_base = n_base
         case = sharded_case(args, device, world, rank, spg, cpu_group)
         # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
@@ -996,9 +1010,13 @@ def run_sharded(args, device, ggnn, world, rank):
         # ... and the one-handle form (in-engine RCCL) in a child process of rank 0
         inproc = None
         if not args.no_in_process and n_base == main_base:
-            if rank == 0:
-                inproc = in_process_child(args, n_base, args.in_process_timeout)
-            barrier()
+            if still_time(args.optional_budget_s):
+                if rank == 0:
+                    inproc = in_process_child(args, n_base, args.in_process_timeout)
+                barrier()
+            else:
+                skipped.append(f"in_process_handle: run already longer than "
+                               f"{args.optional_budget_s:.0f} s")
         case["one_gpu_same_base"] = one
         case["speedup_vs_one_gpu_same_base"] = speedups(case, one)
         if inproc is not None:
@@ -1052,6 +1070,8 @@ def run_sharded(args, device, ggnn, world, rank):
         for k_ in ("saturated_batch_error", "pipelined_error"):
             if k_ in main:
                 out[k_] = main[k_]
+        if skipped:
+            out["skipped_optional_parts"] = skipped
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 
@@ -1070,7 +1090,10 @@ def main():
                     help="N>1: skip the one-handle set_gpus([...]) form (in-engine RCCL)")
     ap.add_argument("--in-process", action="store_true",
                     help="run ONLY the one-handle form over --gpus GPUs in this process")
-    ap.add_argument("--in-process-timeout", type=float, default=420.0)
+    ap.add_argument("--in-process-timeout", type=float, default=300.0)
+    ap.add_argument("--optional-budget-s", type=float, default=330.0,
+                    help="N>1: the one-handle child is skipped when the run is already longer than "
+                         "this, the secondary base 90 s later (the line matters more)")
     ap.add_argument("--n-query", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=10)
