@@ -212,3 +212,22 @@ def test_reference_python_examples_api_conformance():
                 assert kw.arg in params, f"{path}: keyword {kw.arg} not accepted by {f.attr}"
                 checked += 1
     assert checked > 30
+
+
+def test_prescreen_code_rows_never_straddle_more_lines_than_needed(lib):
+    """ggnn_prescreen_sizes (host only): the code-row pitch is a power of two up to 64 bytes and a
+    multiple of 64 above, always >= D and < 2 D -- a 96-byte pitch cost 1.40x the algorithmic
+    bytes on the fabric (profiles/r03_d96_*)."""
+    import ctypes as C
+    dc, pf, sf = C.c_uint32(), C.c_size_t(), C.c_size_t()
+    for D in range(4, 4097, 4):
+        assert lib.ggnn_prescreen_sizes(1000, D, 0, C.byref(dc), C.byref(pf), C.byref(sf)) == 0
+        v = dc.value
+        assert D <= v < max(2 * D, 17) and v % 16 == 0
+        if D <= 64:
+            assert v & (v - 1) == 0            # several whole rows per 128-byte line
+        else:
+            assert v % 64 == 0                 # rows start on 64-byte granules
+        assert pf.value == 8 + v
+    # D not a multiple of 4 is refused (float4 accesses)
+    assert lib.ggnn_prescreen_sizes(1000, 65, 0, C.byref(dc), C.byref(pf), C.byref(sf)) != 0
