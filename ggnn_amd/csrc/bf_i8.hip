@@ -70,8 +70,15 @@ GGNN_DEV int i8v2_qrow(int r, int h)
   return (r & 3) + 8 * (r >> 2) + 4 * h;  // query row of accumulator register r in half-wave h
 }
 
-template <int NM, int KPT>
-__global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
+// LEAN: a register diet for the 16-entry sets, which otherwise need 269 registers = ONE wave per
+// SIMD (5.96 ms for k = 16): the accumulator offsets are read from LDS into the accumulators for
+// every tile instead of living in 32 VGPRs, one staging register set instead of two, no second
+// B-operand set -- 222 registers, two waves per SIMD, 3.92 ms.  The 4- and 10-entry kernels fit two
+// waves anyway and are slower on the diet (k = 10: 3.24 vs 3.06 ms, also when forced to three
+// waves per SIMD, which costs 14 spilled registers): they keep the offsets in registers.
+template <int NM, int KPT, bool LEAN>
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(2))) bf_i8v2_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   uint8_t* lds_b = reinterpret_cast<uint8_t*>(lds_f);
@@ -93,7 +100,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   const uint32_t qw = (blockIdx.x * 4 + wave) * 64;
   const uint32_t begin = blockIdx.y * a.rows_per_slice;
   const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
-  int* hq_w = hq_l + wave * 64;
+  int* hq_w = hq_l + wave * 64;   // LEAN: in matrix order [set][half][register], negated
   int* qn_w = qn_l + wave * 64;
   int* te_w = te_l + wave * 64;
   int* pc_w = pc_l + wave * 64;
@@ -144,7 +151,9 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
       }
     }
   }
-  i32x16 cinit[2];
+  i32x16 cinit[2];  // (LEAN: unused, the offsets stay in LDS)
+  // query (lane & 31) of a set sits in accumulator register (q & 3) + 4 (q >> 3) of half (q >> 2) & 1
+  const int my_slot = (lane & 32) + 16 * ((lane >> 2) & 1) + (lane & 3) + 4 * ((lane & 31) >> 3);
 
   auto refresh_offsets = [&]() {
     I8_T0();
@@ -153,16 +162,30 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
     hq_used = c >> 1;
     Te_seen = Te;
     offsets_stale = false;
-    hq_w[lane] = hq_used;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (LEAN) {
+      hq_w[my_slot] = -hq_used;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    else {
+      hq_w[lane] = hq_used;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        cinit[s2][r] = -hq_w[s2 * 32 + i8v2_qrow(r, h)];
-    __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r)
+          cinit[s2][r] = -hq_w[s2 * 32 + i8v2_qrow(r, h)];
+      __builtin_amdgcn_wave_barrier();
+    }
     I8_T1(9);
+  };
+  // offsets of set s2 as this lane's accumulators want them
+  auto load_offsets = [&](int s2) __attribute__((always_inline)) -> i32x16 {
+    const i32x4* p = reinterpret_cast<const i32x4*>(hq_w + s2 * 32 + 16 * h);
+    const i32x4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    return i32x16{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3],
+                  a2[0], a2[1], a2[2], a2[3], a3[0], a3[1], a3[2], a3[3]};
   };
 
   // applies the pending candidates of all 64 queries in lockstep: one sorted insertion per
@@ -234,8 +257,8 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   // latency and two workgroups per CU the kernel ran at the speed of its dependent loads, the
   // waves waiting 54 % of their time); the bytes are shifted to signed on their way into LDS.
   constexpr int PPT = SR / 32;  // pieces per thread
-  uint4 sva[PPT], svb[PPT];
-  int bna, bnb;
+  uint4 sva[PPT], svb[PPT];  // (LEAN: only the first set)
+  int bna, bnb = 0;
   auto stage_load = [&](uint32_t row0, uint4 (&v)[PPT], int& bn) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < PPT; ++e) {
@@ -273,7 +296,8 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70);
   // stage 1 goes into flight now (set b); stage st + 2 is requested at the top of stage st
-  stage_load(begin + SR, svb, bnb);
+  if constexpr (!LEAN)
+    stage_load(begin + SR, svb, bnb);
 
   // Hits of one tile-set, in the matrix layout: a lane whose accumulator r passed the test
   // appends (2 q'.b' - |b'|^2, row index) to the pending list of query (r, h), the slot taken with
@@ -301,7 +325,7 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
           // the offsets are at most a few tiles stale -- the batch update decides)
           const int slot = atomicAdd(pc_w + q, 1);
           if (slot < kI8v2Pend) {
-            pd_w[slot * 64 + q] = 2 * (acc[r] - off[r]) - bnv;
+            pd_w[slot * 64 + q] = 2 * (acc[r] - off[r]) - bnv;  // (off: the tile's offsets)
             pi_w[slot * 64 + q] = id;
             I8_STAT(2, 1);
           }
@@ -411,10 +435,65 @@ __global__ void __launch_bounds__(256) bf_i8v2_kernel(const BfMfmaArgs a)
     I8_STAT(15, clock64() - t_end1);
 #endif
   };
-  for (uint32_t st = 0; st < nstages; st += 2) {
-    stage_body(st, sva, bna, svb, bnb);
-    if (st + 1 < nstages)
-      stage_body(st + 1, svb, bnb, sva, bna);
+  if constexpr (!LEAN) {
+    for (uint32_t st = 0; st < nstages; st += 2) {
+      stage_body(st, sva, bna, svb, bnb);
+      if (st + 1 < nstages)
+        stage_body(st + 1, svb, bnb, sva, bna);
+    }
+  }
+  else {
+    for (uint32_t st = 0; st < nstages; ++st) {
+      const uint32_t row0 = begin + st * SR;
+      const uint32_t buf = st & 1;
+      const uint8_t* blk = lds_b + buf * stage_bytes;
+      if (st && st % kI8v2Refresh == 0)
+        refresh();
+      if (st + 1 < nstages)
+        stage_load(row0 + SR, sva, bna);  // written to the other buffer at the end of this stage
+#pragma unroll
+      for (int t = 0; t < (int)(SR / kBfTileRows); ++t) {
+        if (row0 + t * kBfTileRows >= end)
+          break;  // uniform
+        if (offsets_stale)
+          refresh_offsets();
+        const uint8_t* trow = blk + (t * kBfTileRows + j) * kBfI8RowStride;
+        i32x4 b[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+          b[m] = *reinterpret_cast<const i32x4*>(trow + 32 * m + 16 * h);
+        i32x16 acc[2];
+        acc[0] = load_offsets(0);
+        acc[1] = load_offsets(1);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[0][m], b[m], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq[1][m], b[m], acc[1], 0, 0, 0);
+        }
+        const int bnv = bns[buf * SR + t * kBfTileRows + j];
+        const int b0 = (bnv == 0x3fffffff) ? 0x7fffffff : (bnv >> 1);
+        int mx0 = acc[0][0], mx1 = acc[1][0];
+#pragma unroll
+        for (int r = 1; r < 16; r += 2) {
+          mx0 = max(max(mx0, acc[0][r]), acc[0][(r + 1) & 15]);
+          mx1 = max(max(mx1, acc[1][r]), acc[1][(r + 1) & 15]);
+        }
+        I8_STAT(5, 2);
+        if (__any(mx0 > b0)) {
+          I8_STAT(0, 1);
+          const i32x16 off = load_offsets(0);
+          tile_set(acc[0], off, 0, bnv, b0, static_cast<int>(row0 + t * kBfTileRows) + j);
+        }
+        if (__any(mx1 > b0)) {
+          I8_STAT(0, 1);
+          const i32x16 off = load_offsets(1);
+          tile_set(acc[1], off, 1, bnv, b0, static_cast<int>(row0 + t * kBfTileRows) + j);
+        }
+      }
+      if (st + 1 < nstages)
+        stage_store((st + 1) & 1, sva, bna);
+      __syncthreads();
+    }
   }
 
 #ifdef GGNN_I8_STATS
@@ -461,9 +540,9 @@ void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint
   const uint32_t KP = m.KP;
   GGNN_REQUIRE(KP == 4 || KP == 10 || KP == 16, GGNN_INVALID_ARGUMENT, "unsupported list length");
 #define GGNN_I8V2(NM_)                                                                        \
-  (KP == 4    ? reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 4>)                        \
-   : KP == 10 ? reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 10>)                       \
-              : reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 16>))
+  (KP == 4    ? reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 4, false>)                 \
+   : KP == 10 ? reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 10, false>)                \
+              : reinterpret_cast<const void*>(&bf_i8v2_kernel<NM_, 16, true>))
   const void* kern =
       nm == 1 ? GGNN_I8V2(1) : nm == 2 ? GGNN_I8V2(2) : nm == 3 ? GGNN_I8V2(3) : GGNN_I8V2(4);
 #undef GGNN_I8V2
