@@ -195,3 +195,19 @@ def test_build_and_query_recall(orc, small_graph):
     assert rec > 0.97
     assert (np.diff(d, axis=1) >= 0).all()
     assert (npop <= 400).all() and (nd >= 32).all()
+
+
+def test_oracle_build_regression_fixture(orc):
+    """tests/golden/oracle_build.json: digests of orc.build on seeded data.  Guards the oracle --
+    the anchor of every GPU parity test -- against accidental change; it pins nothing to the
+    reference (which has no runnable build here)."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_build_golden",
+                                                  os.path.join(here, "make_oracle_build_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for entry in json.load(open(os.path.join(here, "oracle_build.json"))):
+        assert mod.digest(entry["case"]) == entry["digest"], entry["case"]
