@@ -10,12 +10,16 @@ query set (10 000 x 128 f32, k=10) against the resident graph; inputs are in HBM
 region starts.
 
 N = 1: BASELINE.json configs[1] (1M x 128 f32, k_build 24, tau_b 0.5; k = 10) on one MI355X.
-N > 1: STRONG scaling on a FIXED base of 8 shards x 1M points (BASELINE configs[3]/[4] shape:
-the base partitioned across the GPUs of one node).  Rank r owns shards [r*8/N, (r+1)*8/N) as
-resident shards of one engine, every rank searches the full query set in its shards, the sorted
-per-rank candidates are exchanged with ONE RCCL all-gather and merged on the device.  `value` is
-queries/s (Nq / T), not shard-searches; the same line carries the one-GPU figure for the SAME base
-(all 8 shards resident on rank 0's GPU, measured in the same run) and the speed-up over it.
+N > 1: STRONG scaling on the north star's FIXED base: 100M points = 8 shards x 12.5M x 128 f32
+(BASELINE configs[3]/[4] shape: the base partitioned across the GPUs of one node; --n-base sets
+the shard size, a second series on 8 x 1M is carried as `secondary_base`).  Rank r owns shards
+[r*8/N, (r+1)*8/N) as resident shards of one engine, every rank searches the full query set in its
+shards, the sorted per-rank candidates are exchanged with ONE packed RCCL all-gather and merged on
+the device.  `value` is queries/s (Nq / T of blocking 10k-query steps), not shard-searches; the
+same line carries a saturating 100k-query batch and two batches in flight, the one-GPU point of
+the SAME base in the same three modes (all 8 shards resident on rank 0's GPU, measured in the
+same run) with the like-with-like speed-ups, the one-handle form (set_gpus([...]), in-engine
+RCCL; a child process of rank 0) and the aggregate HBM roofline figure.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- SURVEY 8(d): the query kernel's own algorithmic bytes per launch (from its live
