@@ -334,34 +334,62 @@ struct SortedList {
       return;
     // logical index of the entry in physical slot BEST; Q1: nothing shifts into it
     const int qlane = head_in ? BEST + (P - head_in) : -1;
-    const int lane = threadIdx.x;
+    if constexpr (R >= 16) {
+      // long lists: the registers are walked in groups of four with two wave-uniform skips --
+      // groups beyond SORTED hold nothing (R comes in steps of 16), and once the lowest
+      // register of a best-list group had nothing to shift, nothing below shifts either (the
+      // list is sorted).  One branch per FOUR registers: a branch per register serialises the
+      // DPP / readlane chains of neighbouring registers and costs more than it skips
+      // (K = 1000: 118 ms against 108 without any skip), a `break` sends the arrays to scratch.
+      bool settled = false;
 #pragma unroll
-    for (int r = R - 1; r >= 0; --r) {
-      const int i = r * kWave + lane;
-      int pk = lane_up1(key[r]);
-      float pd = lane_up1(dist[r]);
-      if (r > 0) {
-        const int bk = rdlane(key[r - 1], 63);
-        const float bd = rdlanef(dist[r - 1], 63);
-        if (lane == 0) {
-          pk = bk;
-          pd = bd;
-        }
-      }
-      const bool first = (i == 0) || (i == BEST);
-      const bool active = (dist[r] >= d) && (i < SORTED);
-      const bool prev_active = !first && (pd >= d);
-      if (active) {
-        if (first || !prev_active) {
-          key[r] = k;
-          dist[r] = d;
-        }
-        else if (i != qlane && pk != kEmptyKey) {
-          key[r] = pk;
-          dist[r] = pd;
-        }
+      for (int g = R / 4 - 1; g >= 0; --g) {
+        if (g * 4 * kWave >= SORTED || settled)
+          continue;
+        bool low_active = false;
+#pragma unroll
+        for (int r = g * 4 + 3; r >= g * 4; --r)
+          low_active = push_step(r, k, d, qlane);
+        if ((g * 4 + 1) * kWave <= BEST && !__any(low_active))
+          settled = true;
       }
     }
+    else {
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r)
+        push_step(r, k, d, qlane);
+    }
+  }
+
+  // one register of push(): entry i takes (k, d) at the insertion point, its lower neighbour above
+  GGNN_DEV bool push_step(const int r, const int k, const float d, const int qlane)
+  {
+    const int lane = threadIdx.x;
+    const int i = r * kWave + lane;
+    int pk = lane_up1(key[r]);
+    float pd = lane_up1(dist[r]);
+    if (r > 0) {
+      const int bk = rdlane(key[r - 1], 63);
+      const float bd = rdlanef(dist[r - 1], 63);
+      if (lane == 0) {
+        pk = bk;
+        pd = bd;
+      }
+    }
+    const bool first = (i == 0) || (i == BEST);
+    const bool active = (dist[r] >= d) && (i < SORTED);
+    const bool prev_active = !first && (pd >= d);
+    if (active) {
+      if (first || !prev_active) {
+        key[r] = k;
+        dist[r] = d;
+      }
+      else if (i != qlane && pk != kEmptyKey) {
+        key[r] = pk;
+        dist[r] = pd;
+      }
+    }
+    return active;
   }
 
   // KBestList::add_unique, k_best_list.cuh:77-109 (stable insert after equal distances, no

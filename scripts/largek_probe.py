@@ -1,4 +1,4 @@
-"""query time vs KQuery (register-resident list R=1/2/4, LDS-resident list above 239)"""
+"""query time vs KQuery (register-resident list R = 1..32 up to K = 2031, LDS-resident list above)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
