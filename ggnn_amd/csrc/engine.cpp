@@ -1054,6 +1054,25 @@ struct ggnn_handle {
     exchange(lane, nq, k_query, row, ids_out, dists_out, /*blocking=*/true);
   }
 
+  // Grows one exchange buffer of a lane.  Batches in flight on the lane may still use the old
+  // allocation -- also from ANOTHER GPU's stream (peer copies read r_pack, RCCL kernels write
+  // g_pack), which the hipFree of the owning device does not wait for: every GPU's stream of the
+  // lane is drained first.  Rare: the first batch on a lane, or a larger one than any before.
+  void grow_lane(DeviceCtx& owner, int lane, DeviceBuffer& b, size_t bytes)
+  {
+    if (b.bytes >= bytes)
+      return;
+    for (DeviceCtx& ctx : devs) {
+      hipStream_t st = ctx.lane_stream(lane);
+      if (!st)
+        continue;
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    owner.activate();
+    b.alloc(bytes);
+  }
+
   // Combines the per-GPU rows of one lane into the caller's [Nq, K] arrays.  blocking: waits and
   // copies through pinned staging; otherwise everything is only enqueued on the lane's streams
   // (the caller's arrays are written by asynchronous copies: device or page-locked memory).
@@ -1138,8 +1157,8 @@ struct ggnn_handle {
     const size_t part = nq * row;
     for (DeviceCtx& ctx : devs) {
       ctx.activate();
-      DeviceCtx::grow(ctx.xb[lane].g_pack, G * 2 * part * 4);
-      DeviceCtx::grow(ctx.xb[lane].m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
+      grow_lane(ctx, lane, ctx.xb[lane].g_pack, G * 2 * part * 4);
+      grow_lane(ctx, lane, ctx.xb[lane].m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
     }
     GGNN_RCCL_CHECK(rccl.GroupStart());
     ncclResult_t first_error = ncclSuccess;
@@ -1192,8 +1211,8 @@ struct ggnn_handle {
     d0.activate();
     hipStream_t st = d0.lane_stream(lane);
     DeviceCtx::ExchangeBufs& x = d0.xb[lane];
-    DeviceCtx::grow(x.g_pack, G * 2 * part * 4);
-    DeviceCtx::grow(x.m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
+    grow_lane(d0, lane, x.g_pack, G * 2 * part * 4);
+    grow_lane(d0, lane, x.m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
     for (size_t g = 0; g < G; ++g) {
       if (g)
         GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[g].xb[lane].done, 0));
@@ -1288,7 +1307,7 @@ struct ggnn_handle {
       const void* q_here = d_query;
       if (!(loc == GGNN_GPU && q_gpu == ctx.device &&
             (reinterpret_cast<uintptr_t>(d_query) & 15u) == 0)) {
-        DeviceCtx::grow(x.q_stage, qbytes);
+        grow_lane(ctx, lane, x.q_stage, qbytes);
         GGNN_HIP_CHECK(hipMemcpyAsync(x.q_stage.p, d_query, qbytes, hipMemcpyDefault, st));
         q_here = x.q_stage.p;
       }
@@ -1297,7 +1316,7 @@ struct ggnn_handle {
       if (&ctx != &devs[0] && devs[0].xb[lane].consumed)
         GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[0].xb[lane].consumed, 0));
 #endif
-      DeviceCtx::grow(x.r_pack, 2 * part * 4);
+      grow_lane(ctx, lane, x.r_pack, 2 * part * 4);
       int32_t* r = x.r_pack.as<int32_t>();
       enqueue_local_search(ctx, lane, q_here, nq, k_query, tau_query, max_iterations, measure, r,
                            reinterpret_cast<float*>(r + part));

@@ -582,3 +582,28 @@ def test_query_async_multi_gpu_many_batches_in_flight():
         for i, t in enumerate(tickets):
             want = ra if i % 2 == 0 else rb
             assert torch.equal(t.ids.cpu(), want[0]) and torch.equal(t.dists.cpu(), want[1]), (rounds, i)
+
+
+def test_query_async_growing_batches_on_one_slot():
+    """A larger batch than any before re-allocates the lane's buffers while smaller batches of the
+    same lane are in flight; the peer copies / RCCL kernels of ANOTHER GPU may still use the old
+    allocations, which the owning device's hipFree does not wait for -- the engine drains the
+    lane on every GPU before it grows a buffer.  (Two contexts on one device here: the logic runs,
+    the cross-device window itself needs a second GPU.)"""
+    import ggnn_amd as ggnn
+    from bench import synthetic
+    dev_ = torch.device("cuda", 0)
+    N, D, K = 200_000, 128, 10
+    base = synthetic("lowrank16", N, D, 21, dev_)
+    q = synthetic("lowrank16", 8000, D, 22, dev_)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_gpus([0, 0])
+    eng.set_shard_size(50_000)
+    eng.build(24, 0.5, 1)
+    sizes = [500, 1000, 3000, 8000, 2000]
+    want = [eng.query(q[:n].contiguous(), K, 0.9, 175) for n in sizes]
+    tickets = [eng.query_async(q[:n].contiguous(), K, 0.9, 175, slot=0) for n in sizes]
+    eng.synchronize()
+    for n, t, w in zip(sizes, tickets, want):
+        assert torch.equal(t.ids.cpu(), w[0]) and torch.equal(t.dists.cpu(), w[1]), n
