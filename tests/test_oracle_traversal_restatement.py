@@ -495,3 +495,22 @@ def test_sym_prefix_equals_python_restatement(orc, KB, layer):
     assert np.array_equal(atom_a.astype(np.int64), atom_b)
     assert np.array_equal(buf_a.astype(np.int64), buf_b)
     assert atom_b.sum() > 0, "no inverse link was requested: the case tests nothing"
+
+
+def test_cosine_query_equals_python_restatement(orc):
+    """Cosine measure (distance.cuh:139-158: |1 - q.b / sqrt(|q|^2 |b|^2)|, xi = nn1_max * tau,
+    query_layer.cu:48-61).  Small integer coordinates: dot products and norms are exact, the few
+    float32 operations after them are correctly rounded on both sides."""
+    N, D, KB = 2000, 24, 24
+    base = np.random.default_rng(31).integers(1, 16, (N, D)).astype(np.float32)
+    cfg, graph, tr, sel, stats = orc.build(base, KB, 0.5, 1, measure=orc.COSINE,
+                                           rng=orc.make_rng(N, 6))
+    start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
+    q = np.random.default_rng(32).integers(1, 16, (10, D)).astype(np.float32)
+    ids, dists, nd, npop = orc.query(base, q, graph[:N], start, stats, 10, 0.8, 200,
+                                     measure=orc.COSINE, counters=True)
+    for i in range(q.shape[0]):
+        p = py_query(base, q[i], graph[:N], start, stats, 10, 0.8, 200, cosine=True)
+        assert np.array_equal(ids[i], p[0]), i
+        assert dists[i].tobytes() == p[1].tobytes(), i
+        assert (int(nd[i]), int(npop[i])) == (p[2], p[3]), i
