@@ -254,24 +254,29 @@ __global__ void __launch_bounds__(256)
   // Staging: a stage of 128 rows is 1024 pieces of 16 bytes, 4 per thread; threads 0..127 carry
   // the row constants.  Loads run TWO stages ahead of the stage being contracted, in two register
   // sets that alternate (one 8 KB stage per workgroup in flight hid nothing: with ~2 us of memory
-  // latency and two workgroups per CU the kernel ran at the speed of its dependent loads, the
-  // waves waiting 54 % of their time); the bytes are shifted to signed on their way into LDS.
+  // latency and two workgroups per CU the kernel ran at the speed of its dependent loads); the
+  // bytes are shifted to signed on their way into LDS.
   constexpr int PPT = SR / 32;  // pieces per thread
   uint4 sva[PPT], svb[PPT];  // (LEAN: only the first set)
   int bna, bnb = 0;
+  // Every load is UNCONDITIONAL, with a clamped address: a load under `if (row < end)` into a
+  // register that the other path fills with a constant makes the compiler wait for the load
+  // right there (vmcnt(0): the constant may not overtake it), five dependent memory round trips per
+  // stage instead of a prefetch (pipeline-only build: 49 % of the wave cycles parked).  Rows past
+  // the end of the slice repeat its last row and get the norm sentinel when the stage is stored;
+  // columns past D repeat the last 16 and meet zeros in the query operand.
   auto stage_load = [&](uint32_t row0, uint4 (&v)[PPT], int& bn) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < PPT; ++e) {
       const uint32_t p = tid + 256 * e, srow = p >> 3, scol = 16 * (p & 7);
-      v[e] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);  // -> 0 when shifted
-      if (row0 + srow < end && scol < a.D)
-        v[e] = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + srow) * a.D + scol);
+      const uint32_t r = min(row0 + srow, end - 1), c = min(scol, a.D - 16u);
+      v[e] = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(r) * a.D + c);
     }
-    bn = 0x3fffffff;  // rows past the end never pass the accumulator test
-    if (tid < (int)SR && row0 + tid < end)
-      bn = static_cast<int>(a.bnorm[row0 + tid]);
+    bn = static_cast<int>(a.bnorm[min(row0 + (tid & (SR - 1)), end - 1)]);
   };
-  auto stage_store = [&](uint32_t buf, const uint4 (&v)[PPT], int bn) __attribute__((always_inline)) {
+  // row0: first row of the stage being stored
+  auto stage_store = [&](uint32_t buf, uint32_t row0, const uint4 (&v)[PPT], int bn)
+                         __attribute__((always_inline)) {
     uint8_t* t = lds_b + buf * stage_bytes;
 #pragma unroll
     for (int e = 0; e < PPT; ++e) {
@@ -280,8 +285,8 @@ __global__ void __launch_bounds__(256)
           make_uint4(v[e].x ^ 0x80808080u, v[e].y ^ 0x80808080u, v[e].z ^ 0x80808080u,
                      v[e].w ^ 0x80808080u);
     }
-    if (tid < (int)SR)
-      bns[buf * SR + tid] = bn;
+    if (tid < (int)SR)  // rows past the end never pass the accumulator test
+      bns[buf * SR + tid] = (row0 + tid < end) ? bn : 0x3fffffff;
   };
 
 #ifdef GGNN_I8_STATS
@@ -290,14 +295,16 @@ __global__ void __launch_bounds__(256)
   const uint32_t nstages = (end > begin) ? (end - begin + SR - 1) / SR : 0;
   if (nstages) {
     stage_load(begin, sva, bna);
-    stage_store(0, sva, bna);
+    stage_store(0, begin, sva, bna);
   }
   refresh_offsets();
   __syncthreads();
   __builtin_amdgcn_s_waitcnt(0x0F70);
   // stage 1 goes into flight now (set b); stage st + 2 is requested at the top of stage st
-  if constexpr (!LEAN)
-    stage_load(begin + SR, svb, bnb);
+  if constexpr (!LEAN) {
+    if (nstages)
+      stage_load(begin + SR, svb, bnb);
+  }
 
   // Hits of one tile-set, in the matrix layout: a lane whose accumulator r passed the test
   // appends (2 q'.b' - |b'|^2, row index) to the pending list of query (r, h), the slot taken with
@@ -425,7 +432,7 @@ __global__ void __launch_bounds__(256)
     const long long t_end0 = clock64();
 #endif
     if (st + 1 < nstages)
-      stage_store((st + 1) & 1, v_next, bn_next);
+      stage_store((st + 1) & 1, row0 + SR, v_next, bn_next);
 #ifdef GGNN_I8_STATS
     const long long t_end1 = clock64();
 #endif
@@ -491,7 +498,7 @@ __global__ void __launch_bounds__(256)
         }
       }
       if (st + 1 < nstages)
-        stage_store((st + 1) & 1, sva, bna);
+        stage_store((st + 1) & 1, row0 + SR, sva, bna);
       __syncthreads();
     }
   }
