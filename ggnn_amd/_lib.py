@@ -88,6 +88,9 @@ SIGNATURES = {
     "ggnn_get_shard_layout": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_last_query_rows_read": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_device_clock_hz": (_int, [_int, C.POINTER(C.c_double)]),
+    "ggnn_set_hook": (_int, [C.c_char_p, C.c_int64]),
+    "ggnn_reset_hook": (_int, [C.c_char_p]),
+    "ggnn_get_hook": (_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "ggnn_set_log_level": (None, [_int]),
     "ggnn_graph_config_init": (_int, [_u32, _u32, _u32, _cfgp]),
     "ggnn_query_sizing": (_int, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
@@ -144,6 +147,43 @@ def lib():
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def set_hook(name, value):
+    """ggnn_set_hook: process-wide test / tuning hook (names in include/ggnn_c.h)"""
+    st = lib().ggnn_set_hook(name.encode(), int(value))
+    if st != 0:
+        raise ValueError(f"unknown hook {name!r}")
+
+
+def reset_hook(name):
+    st = lib().ggnn_reset_hook(name.encode())
+    if st != 0:
+        raise ValueError(f"unknown hook {name!r}")
+
+
+def get_hook(name):
+    v = C.c_int64()
+    if lib().ggnn_get_hook(name.encode(), C.byref(v)) != 0:
+        raise ValueError(f"unknown hook {name!r}")
+    return int(v.value)
+
+
+class hooks:
+    """with hooks(VIS_SLOTS=1, QUERY_PAIRED=0): ...  -- set for the block, reset afterwards"""
+
+    def __init__(self, **values):
+        self.values = values
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            set_hook(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.values:
+            reset_hook(k)
+        return False
 
 
 def check(status, handle=None):

@@ -312,7 +312,7 @@ class GGNN:
         the caller does with its own references -- a temporary passed as `query`, or a
         rebound loop variable, cannot be recycled under a running kernel."""
         t = _as_tensor(query, what="query")
-        if self._num_gpus > 1 or os.environ.get("GGNN_EXCHANGE") == "rccl":
+        if self._num_gpus > 1 or _lib.get_hook("EXCHANGE") == 1:
             # several GPUs (or the forced RCCL path of the tests): merged [Nq, k] results; host-side tensors are page-locked so that the
             # engine's copies stay asynchronous
             if not t.is_cuda and not t.is_pinned():

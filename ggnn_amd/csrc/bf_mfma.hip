@@ -36,7 +36,10 @@
 //   preceded by KP > K rows of its own slice in exact (distance, index) order: nothing to check.
 #include <cstdlib>
 
+#include <mutex>
+
 #include "bf_common.hpp"
+#include "hooks.hpp"
 
 namespace ggnn_amd {
 
@@ -1018,14 +1021,17 @@ bool bf_mfma_supported(const BfLaunch& a)
 // Per-call scratch comes from a PRIVATE stream-ordered pool per device (not the device's default
 // pool, whose settings belong to the rest of the process): freed blocks stay in it up to a
 // bounded amount, so repeated bf_query calls cost no allocation, and nothing else in the process
-// is affected.  GGNN_BF_POOL_KEEP_MB sets the amount kept (default 1024).
+// is affected.  Hook BF_POOL_KEEP_MB sets the amount kept (default 1024).  Creation is serialised:
+// two handles (or threads) may reach their first bf_query on one device at the same time.
 static hipMemPool_t scratch_pool()
 {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
     return nullptr;
+  static std::mutex mtx;
   static hipMemPool_t pools[64] = {};
   static bool tried[64] = {};
+  std::lock_guard<std::mutex> lock(mtx);
   if (!tried[dev]) {
     tried[dev] = true;
     hipMemPoolProps props{};
@@ -1035,9 +1041,8 @@ static hipMemPool_t scratch_pool()
     props.location.id = dev;
     hipMemPool_t pool = nullptr;
     if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
-      uint64_t keep = 1024ull << 20;
-      if (const char* e = std::getenv("GGNN_BF_POOL_KEEP_MB"))
-        keep = static_cast<uint64_t>(std::max(0, std::atoi(e))) << 20;
+      uint64_t keep = static_cast<uint64_t>(std::clamp<int64_t>(hook(kHookBfPoolKeepMb), 0, 1 << 20))
+                      << 20;
       (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
       pools[dev] = pool;
     }
@@ -1067,10 +1072,10 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   // all but near-degenerate queries; correctness does not depend on the value
   // uint8 + squared L2 with rows of up to 128 bytes: integer contraction on the i8 matrix path;
   // lists of up to 24 entries live in registers (bf_i8v2_kernel), longer ones in LDS
-  // (bf_mfma_i8_kernel; GGNN_BF_I8_V1=1 forces that one: A/B hook)
+  // (bf_mfma_i8_kernel; hook BF_I8_V1 = 1 forces that one: A/B hook)
   const bool use_i8 = a.dtype == GGNN_U8 && a.measure == GGNN_EUCLIDEAN && a.D <= 128 &&
-                      std::getenv("GGNN_BF_NO_I8") == nullptr;
-  const bool use_i8v2 = use_i8 && a.k_query <= 16 && std::getenv("GGNN_BF_I8_V1") == nullptr;
+                      hook(kHookBfNoI8) == 0;
+  const bool use_i8v2 = use_i8 && a.k_query <= 16 && hook(kHookBfI8V1) == 0;
   // (integer arithmetic needs no certificate margin: the register sets hold exactly K rounded up)
   const uint32_t KP = use_i8v2 ? (a.k_query <= 4 ? 4u : a.k_query <= 10 ? 10u : 16u)
                                : a.k_query + 8;
@@ -1085,16 +1090,16 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   // second round costs more than the lower parallelism (measured: 790 blocks 39.8 ms, 474 blocks
   // 31.5 ms for 10k x 1M x 128)
   uint32_t slices = std::max(1u, std::min(32u, 512u / std::max(1u, qblocks)));
-  if (const char* e = std::getenv("GGNN_BF_SLICES"))  // tuning hook
-    slices = std::max(1u, std::min(64u, static_cast<uint32_t>(std::atoi(e))));
+  if (const int64_t hs = hook(kHookBfSlices); hs > 0)  // tuning hook
+    slices = static_cast<uint32_t>(std::clamp<int64_t>(hs, 1, 64));
   uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
 
-  // float32 squared L2: rows are shifted by a column mean of the base (GGNN_BF_NO_CENTER=1: test
+  // float32 squared L2: rows are shifted by a column mean of the base (hook BF_NO_CENTER = 1: test
   // hook that leaves them unshifted so that offset data exercises the re-scan)
   const bool center = a.dtype == GGNN_F32 && a.measure == GGNN_EUCLIDEAN &&
-                      std::getenv("GGNN_BF_NO_CENTER") == nullptr;
+                      hook(kHookBfNoCenter) == 0;
 
   // one scratch block: [norms N+Nq][mean D][mean partials 256 D][bn_max, rescan_count]
   // [rescan_list Nq][part ids][part dists][re-scan slices ids][re-scan slices dists]
@@ -1168,10 +1173,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   m.DM = a.D > 128 ? (a.D + 3) / 4 * 4 : 0;  // the chunked kernel keeps the shift vector in LDS
   const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
-  // rows longer than one chunk: base tiles per accumulator group (GGNN_BF_TILES=2|4 tuning hook)
-  int tiles_per_group = 2;
-  if (const char* e = std::getenv("GGNN_BF_TILES"))
-    tiles_per_group = std::atoi(e) == 4 ? 4 : 2;
+  // rows longer than one chunk: base tiles per accumulator group (hook BF_TILES = 2 | 4)
+  const int tiles_per_group = hook(kHookBfTiles) == 4 ? 4 : 2;
 
   BfRerankArgs rr{};
   rr.base = a.base;
@@ -1224,12 +1227,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                        static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr));
   }
   if (use_i8v2) {
-    m.gthr = std::getenv("GGNN_BF_I8_NOSHARE") ? nullptr : gthr;  // (A/B hook)
-    // GGNN_BF_I8_WARM=<rows>: seeding launch over the head of the base (tuning hook; off: a
+    m.gthr = hook(kHookBfI8NoShare) ? nullptr : gthr;  // (A/B hook)
+    // hook BF_I8_WARM = <rows>: seeding launch over the head of the base (tuning hook; off: a
     // 40-workgroup launch costs more than the per-slice cold starts it saves)
-    const uint32_t warm = std::getenv("GGNN_BF_I8_WARM")
-                              ? static_cast<uint32_t>(std::atoi(std::getenv("GGNN_BF_I8_WARM")))
-                              : 0u;
+    const uint32_t warm = static_cast<uint32_t>(
+        std::clamp<int64_t>(hook(kHookBfI8Warm), 0, static_cast<int64_t>(a.N_base)));
     launch_bf_i8v2(m, qblocks, slices, warm, stream);
   }
   else if (use_i8) {

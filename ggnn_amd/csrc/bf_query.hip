@@ -9,6 +9,7 @@
 // for large query batches is planned on top of this parity anchor, see DESIGN.md.)
 #include <cstdlib>
 
+#include "hooks.hpp"
 #include "traversal.hpp"
 
 namespace ggnn_amd {
@@ -306,11 +307,8 @@ void launch_bf_query(const BfLaunch& a, hipStream_t stream)
     GGNN_HIP_CHECK(hipMemsetAsync(a.n_rescanned, 0, sizeof(uint32_t), stream));
   if (a.Nq == 0)
     return;
-  // large batches: Q x B^T on the matrix cores (bf_mfma.hip); GGNN_BF_SCAN=1 forces the scan
-  static const bool force_scan = [] {
-    const char* e = std::getenv("GGNN_BF_SCAN");
-    return e && e[0] == '1';
-  }();
+  // large batches: Q x B^T on the matrix cores (bf_mfma.hip); hook BF_SCAN = 1 forces the scan
+  const bool force_scan = hook(kHookBfScan) == 1;
   if (!force_scan && bf_mfma_supported(a)) {
     launch_bf_query_mfma(a, stream);
     return;

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "hooks.hpp"
 
 namespace ggnn_amd {
 
@@ -225,12 +227,16 @@ struct Rccl {
     return r;
   }
 };
+// a failed RCCL call: the only kind of error the exchange answers with its peer-copy fallback
+struct RcclError : Error {
+  using Error::Error;
+};
 #define GGNN_RCCL_CHECK(expr)                                                              \
   do {                                                                                     \
     ncclResult_t _r = (expr);                                                              \
     if (_r != ncclSuccess)                                                                 \
-      throw ::ggnn_amd::Error(GGNN_DEVICE_ERROR, std::string(#expr) + ": " +               \
-                                                     Rccl::get().GetErrorString(_r));      \
+      throw RcclError(GGNN_DEVICE_ERROR, std::string(#expr) + ": " +           \
+                                                         Rccl::get().GetErrorString(_r));  \
   } while (0)
 
 // everything one GPU owns (GPUInstance of the reference, gpu_instance.cuh:60-221, reduced to
@@ -255,7 +261,10 @@ struct DeviceCtx {
   DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
   // Result staging of query() / query_async(): grown on demand, kept between calls.  One set per
   // lane: lanes [0, kShardStreams) belong to the asynchronous slots (their streams), lane
-  // kBlockingLane to the blocking query() on `stream`.  Ids and distance bit patterns share ONE
+  // kBlockingLane to the blocking query(): its staging, exchange and result copies run on `stream`,
+  // but with several resident shards its per-shard search launches are spread over the SAME
+  // shard_stream[] the asynchronous slots use (ordered behind whatever a slot has in flight there;
+  // the blocking call waits for all of them before it returns).  Ids and distance bit patterns share ONE
   // buffer so that the exchange is one collective: r_pack = [ids: Nq x row][dists: Nq x row].
   static constexpr int kBlockingLane = kShardStreams;
   struct ExchangeBufs {
@@ -370,8 +379,7 @@ struct ggnn_handle {
   uint32_t N_shard{0};
   bool return_results_on_gpu{false};
   bool collect_counters{false};
-  bool prescreen{std::getenv("GGNN_PRESCREEN") == nullptr ||
-                 std::string(std::getenv("GGNN_PRESCREEN")) != "0"};
+  bool prescreen{hook(kHookPrescreen) != 0};  // ggnn_set_prescreen() per handle
 
   // deterministic-build hooks (ggnn_set_build_hooks): injected selection random numbers
   // ([layers-1][N_shard], shard-local) and sym launched one point at a time in ascending order
@@ -407,6 +415,7 @@ struct ggnn_handle {
   // one RCCL communicator per GPU of a multi-GPU handle (created with the first exchange)
   std::vector<ncclComm_t> comms;
   int rccl_state{0};  // 0 = not tried, 1 = communicators ready, -1 = unavailable (peer copies)
+  uint32_t rccl_fallbacks{0};  // exchanges that failed inside RCCL and were served by peer copies
   const char* last_exchange{"none"};
 
   ~ggnn_handle() { destroy_comms(); }
@@ -421,14 +430,14 @@ struct ggnn_handle {
   }
   // RCCL needs distinct devices per rank; a handle whose contexts share a device (tests on a
   // one-GPU box) and builds without librccl exchange through peer copies instead.
-  // GGNN_EXCHANGE=rccl|copy forces one of the two (rccl also for a single GPU: a 1-rank world).
+  // Hook EXCHANGE = 1 (rccl) | 2 (copy) forces one of the two (rccl also for a single GPU: a
+  // 1-rank world).
   bool ensure_comms()
   {
     if (rccl_state != 0)
       return rccl_state > 0;
     rccl_state = -1;
-    const char* force = std::getenv("GGNN_EXCHANGE");
-    if (force && std::string(force) == "copy")
+    if (hook(kHookExchange) == 2)
       return false;
     std::vector<int> ids;
     for (const DeviceCtx& ctx : devs)
@@ -714,12 +723,9 @@ struct ggnn_handle {
                     cfg.Ns[layer]};
         // The short sym searches only gain from the pre-screen on wide rows (measured, 1M points:
         // D = 960 cosine 805 -> 454 ms per build, D = 128 74.6 -> 78.2 ms): used from 1 KB rows on.
-        // GGNN_SYM_PRESCREEN=0|1 forces it off / on (tuning hook).
-        static const int sym_ps_env = [] {
-          const char* e = std::getenv("GGNN_SYM_PRESCREEN");
-          return e ? (e[0] == '0' ? 0 : 1) : -1;
-        }();
-        const bool sym_ps = sym_ps_env >= 0 ? sym_ps_env == 1 : pad_D >= 256;
+        // Hook SYM_PRESCREEN = 0 | 1 forces it off / on (tuning hook).
+        const int64_t sym_ps_hook = hook(kHookSymPrescreen);
+        const bool sym_ps = sym_ps_hook >= 0 ? sym_ps_hook == 1 : pad_D >= 256;
         if (use_ps && sym_ps) {
           s.ps_codes = sh.ps_codes.as<uint8_t>();
           s.ps_params = sh.ps_params.as<float>();
@@ -845,8 +851,17 @@ struct ggnn_handle {
     Shard& sh = ctx.shards[si];
     if (!prescreen || base_dtype != GGNN_F32 || pad_D < 64)
       return false;
-    if (sh.ps_state != 0 && sh.ps_measure != measure)
-      sh.ps_state = 0;  // the codes belong to the other measure: code again
+    if (sh.ps_state != 0 && sh.ps_measure != measure) {
+      // the codes belong to the other measure: code again.  Batches still in flight on this GPU
+      // (query_async lanes, overlapped shard launches) read the old codes: drained explicitly
+      // (not left to the hipFree inside DeviceBuffer::alloc, which only happens to synchronise)
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      for (int i = 0; i < DeviceCtx::kShardStreams; ++i)
+        if (ctx.shard_stream[i])
+          GGNN_HIP_CHECK(hipStreamSynchronize(ctx.shard_stream[i]));
+      sh.ps_state = 0;
+    }
     if (sh.ps_state == 0) {
       const uint32_t Dc = prescreen_code_dim(pad_D);
       DeviceBuffer scratch;
@@ -907,12 +922,8 @@ struct ggnn_handle {
     std::vector<uint32_t> h_cnt;
     // Several resident shards: one launch per shard, spread over a few streams and NOT separated
     // by host synchronisation, so the under-occupied tail of a 10k-wave launch is filled by the
-    // next shard's waves (GGNN_SHARD_OVERLAP=0: one launch at a time, as for the work counters).
-    static const bool overlap_env = [] {
-      const char* e = std::getenv("GGNN_SHARD_OVERLAP");
-      return !(e && e[0] == '0');
-    }();
-    const bool overlap = spg > 1 && !collect_counters && overlap_env;
+    // next shard's waves (hook SHARD_OVERLAP = 0: one launch at a time, as for the work counters).
+    const bool overlap = spg > 1 && !collect_counters && hook(kHookShardOverlap) != 0;
     if (overlap) {
       for (uint32_t si = 0; si < spg; ++si)
         (void)ensure_prescreen(ctx, si, measure);  // may code a shard (synchronises): do it first
@@ -1036,8 +1047,7 @@ struct ggnn_handle {
     if (direct)
       return;
 
-    const char* force = std::getenv("GGNN_EXCHANGE");
-    const bool force_rccl = force && std::string(force) == "rccl";
+    const bool force_rccl = hook(kHookExchange) == 1;
     if (devs.size() == 1 && !force_rccl) {
       // ResultMerger::merge for one GPU: first K of each pre-sorted row (result_merger.cpp:55-73)
       DeviceCtx& d0 = devs[0];
@@ -1084,12 +1094,25 @@ struct ggnn_handle {
         exchange_rccl(lane, nq, k_query, row, ids_out, dists_out, blocking);
         return;
       }
-      catch (const Error& e) {
-        // a failed collective leaves the communicators unusable: drop them for good and serve
-        // this and every later call through peer copies
+      catch (const RcclError& e) {
+        // A failed collective leaves the communicators unusable: drop them for good and serve this
+        // and every later call through peer copies.  Only RCCL's own failures take this path (an
+        // out-of-memory or HIP error propagates to the caller).  Other lanes may still have
+        // all-gathers enqueued on these communicators, and after a partial group failure some
+        // ranks hold a collective that will never complete on its own: every stream of every GPU
+        // is drained (best effort) before the communicators go.
         GGNN_LOG(0, "RCCL exchange failed (%s): falling back to peer copies", e.what());
+        for (DeviceCtx& ctx : devs) {
+          ctx.activate();
+          (void)hipStreamSynchronize(ctx.stream);
+          for (int i = 0; i < DeviceCtx::kShardStreams; ++i)
+            if (ctx.shard_stream[i])
+              (void)hipStreamSynchronize(ctx.shard_stream[i]);
+        }
+        (void)hipGetLastError();
         destroy_comms();
         rccl_state = -1;
+        ++rccl_fallbacks;
       }
     }
     exchange_peer_copies(lane, nq, k_query, row, ids_out, dists_out, blocking);
@@ -1159,6 +1182,13 @@ struct ggnn_handle {
       ctx.activate();
       grow_lane(ctx, lane, ctx.xb[lane].g_pack, G * 2 * part * 4);
       grow_lane(ctx, lane, ctx.xb[lane].m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
+    }
+    // fault injection (hook RCCL_FAIL_AFTER = n): the n-th exchange of the process reports an RCCL
+    // failure before anything is enqueued -- the path a real failure takes from here on
+    if (const int64_t fail_at = hook(kHookRcclFailAfter); fail_at > 0) {
+      static std::atomic<int64_t> exchanges{0};
+      if (++exchanges == fail_at)
+        GGNN_RCCL_CHECK(ncclInternalError);
     }
     GGNN_RCCL_CHECK(rccl.GroupStart());
     ncclResult_t first_error = ncclSuccess;
@@ -1275,8 +1305,7 @@ struct ggnn_handle {
         recode = recode || (sh.ps_state != 0 && sh.ps_measure != measure);
     if (recode)
       synchronize();
-    const char* force = std::getenv("GGNN_EXCHANGE");
-    const bool force_rccl = force && std::string(force) == "rccl";
+    const bool force_rccl = hook(kHookExchange) == 1;
     if (devs.size() == 1 && !force_rccl) {
       DeviceCtx& ctx = devs[0];
       GGNN_REQUIRE(loc == GGNN_GPU && q_gpu == ctx.device, GGNN_INVALID_ARGUMENT,
@@ -1626,6 +1655,33 @@ ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable)
 {
   GGNN_NEED_HANDLE(h);
   h->prescreen = enable != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_set_hook(const char* name, int64_t value)
+{
+  const int h = ggnn_amd::hook_by_name(name);
+  if (h < 0)
+    return GGNN_INVALID_ARGUMENT;
+  ggnn_amd::hook_set(static_cast<ggnn_amd::Hook>(h), value);
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_reset_hook(const char* name)
+{
+  const int h = ggnn_amd::hook_by_name(name);
+  if (h < 0)
+    return GGNN_INVALID_ARGUMENT;
+  ggnn_amd::hook_reset(static_cast<ggnn_amd::Hook>(h));
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_get_hook(const char* name, int64_t* value)
+{
+  const int h = ggnn_amd::hook_by_name(name);
+  if (h < 0 || !value)
+    return GGNN_INVALID_ARGUMENT;
+  *value = ggnn_amd::hook(static_cast<ggnn_amd::Hook>(h));
   return GGNN_OK;
 }
 

@@ -1,0 +1,40 @@
+// Test and tuning hooks of libggnn_amd.so: process-wide named integers.
+//
+// Set with ggnn_set_hook(name, value) (include/ggnn_c.h documents every name and its values).
+// The environment is consulted ONLY when GGNN_TEST_HOOKS=1 is set (variable GGNN_<NAME>, read at
+// every use), so that a production process that merely inherits such a variable is not steered
+// by it.  Precedence: ggnn_set_hook > environment (with GGNN_TEST_HOOKS=1) > built-in default.
+#pragma once
+#include <cstdint>
+
+namespace ggnn_amd {
+
+enum Hook {
+  kHookPrescreen = 0,   // PRESCREEN        default of new handles: 1 = exact pre-screen on
+  kHookExchange,        // EXCHANGE         0 auto | 1 "rccl" | 2 "copy"
+  kHookSymPrescreen,    // SYM_PRESCREEN    -1 auto (rows >= 1 KB) | 0 | 1
+  kHookShardOverlap,    // SHARD_OVERLAP    1 = resident shards searched concurrently
+  kHookVisSlots,        // VIS_SLOTS        usable keys per bucket of the hashed visited set (1..8)
+  kHookQueryPaired,     // QUERY_PAIRED     -1 auto | 0 one search per wave | 1 two per wave
+  kHookBfPoolKeepMb,    // BF_POOL_KEEP_MB  release threshold of the bf scratch pool
+  kHookBfNoI8,          // BF_NO_I8         1 = uint8 bf_query through the float kernels
+  kHookBfI8V1,          // BF_I8_V1         1 = LDS-list i8 kernel instead of the register-set one
+  kHookBfSlices,        // BF_SLICES        0 auto | base slices per query block
+  kHookBfNoCenter,      // BF_NO_CENTER     1 = rows not shifted by the column mean
+  kHookBfTiles,         // BF_TILES         2 | 4 base tiles per accumulator group (D > 128)
+  kHookBfI8NoShare,     // BF_I8_NOSHARE    1 = slices do not share their bound
+  kHookBfI8Warm,        // BF_I8_WARM       rows of a seeding launch (0 = none)
+  kHookBfScan,          // BF_SCAN          1 = scan kernels instead of the matrix-core path
+  kHookRcclFailAfter,   // RCCL_FAIL_AFTER  fault injection: the n-th exchange (1-based) reports an
+                        //                  RCCL failure (0 = never); exercises the peer-copy fallback
+  kHookCount
+};
+
+int64_t hook(Hook h);
+const char* hook_name(Hook h);
+// -1: unknown name
+int hook_by_name(const char* name);
+void hook_set(Hook h, int64_t value);
+void hook_reset(Hook h);
+
+}  // namespace ggnn_amd

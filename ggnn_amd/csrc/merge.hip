@@ -246,7 +246,7 @@ void launch_merge(const MergeLaunch& a, hipStream_t stream)
     args.STs_off[l] = c.STs_offsets[l];
   }
   args.tau = a.tau_build;
-  args.vis_slots = vis_slots_from_env();
+  args.vis_slots = vis_slots_hook();
   GGNN_REQUIRE(args.sorted < kMergeCache, GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
   if (!args.N_btm)
     return;

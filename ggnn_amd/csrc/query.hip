@@ -2,29 +2,10 @@
 // Reference: QueryKernel::operator(), src/ggnn/query/query_layer.cu:39-97; host sizing
 // QueryKernelsImpl::query, src/ggnn/query/query_kernels.cu:50-186.
 #include "traversal.hpp"
+#include "query_args.hpp"
 
 namespace ggnn_amd {
 
-struct QueryArgs {
-  const void* base;
-  const void* query;
-  const int32_t* graph0;
-  const int32_t* start;
-  const float* nn1_stats;
-  int32_t* ids;
-  float* dists;
-  uint32_t* n_dist;
-  uint32_t* n_pop;
-  uint2* n_rows;
-  uint32_t D, Nq, N_base, KBuild, num_start, KQuery, sorted, cache, max_iters;
-  uint32_t shards_per_gpu, on_gpu_shard;
-  float tau;
-  // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
-  const uint8_t* ps_codes;
-  const float* ps_params;
-  uint32_t ps_Dc;
-  uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
-};
 
 template <class PSC, typename BaseT>
 GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
@@ -292,6 +273,8 @@ static void launch_query_cfg(const QueryArgs& args, bool use_ps, ggnn_measure me
     launch_query_r<BaseT, LPR, NCH, kCos, NoPrescreen>(args, args.sorted, stream);
 }
 
+constexpr uint32_t kPairedMinQueries = 7 * 1024;
+
 void launch_query(const QueryLaunch& a, hipStream_t stream)
 {
   if (a.Nq == 0)
@@ -320,7 +303,7 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.shards_per_gpu = a.shards_per_gpu;
   args.on_gpu_shard = a.on_gpu_shard;
   args.tau = a.tau_query;
-  args.vis_slots = vis_slots_from_env();
+  args.vis_slots = vis_slots_hook();
   const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
     GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(a.D), GGNN_INVALID_ARGUMENT,
@@ -331,6 +314,19 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
     args.ps_codes = a.ps_codes;
     args.ps_params = a.ps_params;
     args.ps_Dc = a.ps_Dc;
+  }
+
+  // Two searches per wave (query_x2.hip) where that form is instantiated: hook QUERY_PAIRED forces
+  // it on / off, otherwise by batch size -- up to 7 x 1024 queries every one-search wave is
+  // resident at once and more waves mean more parallelism; above that the paired form keeps the
+  // whole batch in ONE resident round (10 240 searches) and gives every SIMD more independent work.
+  {
+    const int64_t paired = hook(kHookQueryPaired);
+    const bool want = paired >= 0 ? paired == 1 : a.Nq > kPairedMinQueries;
+    if (want && launch_query_x2(args, a.dtype, a.measure, use_ps, stream)) {
+      GGNN_HIP_CHECK(hipGetLastError());
+      return;
+    }
   }
 
 #define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)

@@ -1,0 +1,33 @@
+// Kernel arguments of the query kernels (query.hip, query_x2.hip).
+#pragma once
+#include "common.hpp"
+
+namespace ggnn_amd {
+
+struct QueryArgs {
+  const void* base;
+  const void* query;
+  const int32_t* graph0;
+  const int32_t* start;
+  const float* nn1_stats;
+  int32_t* ids;
+  float* dists;
+  uint32_t* n_dist;
+  uint32_t* n_pop;
+  uint2* n_rows;
+  uint32_t D, Nq, N_base, KBuild, num_start, KQuery, sorted, cache, max_iters;
+  uint32_t shards_per_gpu, on_gpu_shard;
+  float tau;
+  // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
+  const uint8_t* ps_codes;
+  const float* ps_params;
+  uint32_t ps_Dc;
+  uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
+};
+
+// query_x2.hip: two searches per wave, phase-interleaved (see the file header).  Returns false when
+// the configuration has no paired instantiation (the caller then launches the one-search kernel).
+bool launch_query_x2(const QueryArgs& args, ggnn_dtype dtype, ggnn_measure measure, bool use_ps,
+                     hipStream_t stream);
+
+}  // namespace ggnn_amd

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "hooks.hpp"
 
 namespace ggnn_amd {
 
@@ -858,15 +859,16 @@ struct StepsOf {
 
 // Computes the distances of the nsurv compacted candidates in lds.ckeys[0,nsurv) and leaves
 // them in lds.cd0[0,nsurv).  Out-of-range chunks are neither loaded nor accumulated.
+// first: candidates [0, first) have been evaluated by the caller already (query_x2.hip).
 template <int MODE, class DE, int STEPS = StepsOf<DE::LPR, DE::NCH>::value>
 GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
-                                const int32_t* translation)
+                                const int32_t* translation, int first = 0)
 {
   constexpr int ROWS = DE::ROWS;
   using Chunk = typename DE::Chunk;
   const int lane = threadIdx.x;
   const int grp = lane / DE::LPR;
-  for (int s0 = 0; s0 < nsurv; s0 += ROWS * STEPS) {
+  for (int s0 = first; s0 < nsurv; s0 += ROWS * STEPS) {
     Chunk v[STEPS][DE::NCH];
     int rr[STEPS];
 #pragma unroll
@@ -1217,16 +1219,12 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
   return fetch<MODE, FILTER>(sl, de, lds, cand, translation, NoPrescreen{}, rows);
 }
 
-// GGNN_VIS_SLOTS=<1..8>: test hook that shrinks the buckets of the hashed visited set so that the
+// hook VIS_SLOTS = <1..8>: test hook that shrinks the buckets of the hashed visited set so that the
 // stash, its overflow into the ring scan and the removal paths are exercised by ordinary searches
-inline uint32_t vis_slots_from_env()
+inline uint32_t vis_slots_hook()
 {
-  if (const char* e = std::getenv("GGNN_VIS_SLOTS")) {
-    const int v = std::atoi(e);
-    if (v >= 1 && v <= kVisSlots)
-      return static_cast<uint32_t>(v);
-  }
-  return kVisSlots;
+  const int64_t v = hook(kHookVisSlots);
+  return (v >= 1 && v <= kVisSlots) ? static_cast<uint32_t>(v) : static_cast<uint32_t>(kVisSlots);
 }
 
 // block-size / chunk configuration by dimension and element type (host side)

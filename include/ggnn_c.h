@@ -156,7 +156,7 @@ ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t
 /* how the last ggnn_query combined the per-GPU results (replaces the D2H + CPU heap merge of
  * ggnn.cu:308-329 / result_merger.cpp:51-149): "none" (one GPU), "rccl" (grouped ncclAllGather
  * over xGMI + per-GPU slice merge) or "copy" (peer copies to the first GPU: contexts sharing one
- * device, or no librccl).  Environment GGNN_EXCHANGE=rccl|copy forces one of them. */
+ * device, or no librccl).  Hook EXCHANGE (ggnn_set_hook) forces one of them. */
 const char* ggnn_last_exchange(const ggnn_t* h);
 /* queries of the last ggnn_bf_query that were answered by the exhaustive scan because the
  * matrix-core pre-selection could not be certified exact (tracing; results are exact either way) */
@@ -166,8 +166,8 @@ ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
  * (4*D bytes each) and, with the pre-screen, 8-bit code rows (prescreen_code_dim(D) bytes each: a power of two up to 64, multiples of 64 above). */
 ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows);
 /* Exact pre-screen of the float32 query and merge kernels (no reference counterpart; results
- * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; the
- * environment variable GGNN_PRESCREEN=0 turns the default off. */
+ * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; hook PRESCREEN = 0
+ * (ggnn_set_hook) turns the default of handles created afterwards off. */
 ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable);
 /* Deterministic build (no reference counterpart; the reference's build is not reproducible:
  * cuRAND stream graph_construction.cu:96-102,168-169, atomics and cross-block reads in sym
@@ -188,6 +188,40 @@ ggnn_status ggnn_get_shard_layout(const ggnn_t* h, uint32_t* num_shards, uint32_
 ggnn_status ggnn_device_clock_hz(int device, double* clock_hz);
 /* nanobind.cu:151 set_log_level */
 void ggnn_set_log_level(int level);
+
+/* Test and tuning hooks (no reference counterpart): process-wide named integers that select a
+ * code path or a tuning constant.  NONE changes a result -- every value yields the same ids and
+ * distances; they exist so that tests can force rarely taken paths and so that A/B measurements
+ * need no rebuild.  Precedence: ggnn_set_hook > the environment variable GGNN_<NAME>, which is
+ * consulted ONLY while GGNN_TEST_HOOKS=1 is set (a production process that merely inherits such a
+ * variable is not steered by it) > the default.  Unknown name: GGNN_INVALID_ARGUMENT.
+ *
+ *   name             default  values
+ *   PRESCREEN           1     default of ggnn_set_prescreen for handles created afterwards
+ *   EXCHANGE            0     0 auto | 1 ("rccl") RCCL all-gather, also on one GPU (1-rank world)
+ *                             | 2 ("copy") peer copies to the first GPU
+ *   SYM_PRESCREEN      -1     sym kernel with the pre-screen: -1 auto (rows >= 1 KB) | 0 | 1
+ *   SHARD_OVERLAP       1     0 = resident shards of one GPU searched one launch at a time
+ *   VIS_SLOTS           8     usable keys per bucket of the hashed visited set, 1..8 (small values
+ *                             exercise stash, overflow and removal paths)
+ *   QUERY_PAIRED       -1     query kernel form: -1 auto (by batch size) | 0 one search per wave
+ *                             | 1 two searches per wave (query_x2.hip) wherever it is instantiated
+ *   BF_POOL_KEEP_MB  1024     bytes the private bf_query scratch pool keeps between calls
+ *   BF_NO_I8            0     1 = uint8 bf_query through the float matrix-core kernels
+ *   BF_I8_V1            0     1 = LDS-list i8 kernel instead of the register-set one
+ *   BF_SLICES           0     0 auto | base slices per query block (1..64)
+ *   BF_NO_CENTER        0     1 = float32 rows not shifted by the column mean (exercises the re-scan)
+ *   BF_TILES            2     2 | 4 base tiles per accumulator group (D > 128)
+ *   BF_I8_NOSHARE       0     1 = slices of the i8 kernel do not share their bound
+ *   BF_I8_WARM          0     rows of a seeding launch of the i8 kernel (0 = none)
+ *   BF_SCAN             0     1 = scan kernels instead of the matrix-core brute force
+ *   RCCL_FAIL_AFTER     0     fault injection: the n-th multi-GPU exchange of the process reports an
+ *                             RCCL failure (exercises the peer-copy fallback); 0 = never */
+ggnn_status ggnn_set_hook(const char* name, int64_t value);
+/* back to environment / default */
+ggnn_status ggnn_reset_hook(const char* name);
+/* the value a use of the hook would see right now */
+ggnn_status ggnn_get_hook(const char* name, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------
  * Section 2: operator seam (device pointers, explicit stream).  `stream` is a hipStream_t.

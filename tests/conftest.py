@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# The library reads its GGNN_<HOOK> environment variables only while this master switch is set
+# (include/ggnn_c.h, "Test and tuning hooks"): the tests that steer a hook through monkeypatch.setenv
+# rely on it; tests/test_cabi.py checks that without the switch the environment is ignored.
+os.environ["GGNN_TEST_HOOKS"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -231,3 +231,39 @@ def test_prescreen_code_rows_never_straddle_more_lines_than_needed(lib):
         assert pf.value == 8 + v
     # D not a multiple of 4 is refused (float4 accesses)
     assert lib.ggnn_prescreen_sizes(1000, 65, 0, C.byref(dc), C.byref(pf), C.byref(sf)) != 0
+
+
+def test_hooks_api(lib, monkeypatch):
+    """ggnn_set_hook / ggnn_get_hook / ggnn_reset_hook; the environment only counts while
+    GGNN_TEST_HOOKS=1 (conftest sets it for the test session)."""
+    from ggnn_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ggnn_c.h")).read()
+    names = ["PRESCREEN", "EXCHANGE", "SYM_PRESCREEN", "SHARD_OVERLAP", "VIS_SLOTS", "QUERY_PAIRED",
+             "BF_POOL_KEEP_MB", "BF_NO_I8", "BF_I8_V1", "BF_SLICES", "BF_NO_CENTER", "BF_TILES",
+             "BF_I8_NOSHARE", "BF_I8_WARM", "BF_SCAN", "RCCL_FAIL_AFTER"]
+    for n in names:
+        assert re.search(r"\*\s+" + n + r"\s", header), f"hook {n} is not documented in ggnn_c.h"
+        _lib.get_hook(n)
+    # every getenv of the product library goes through the registry
+    src_dir = os.path.join(ROOT, "ggnn_amd", "csrc")
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".cpp", ".hpp")) and f != "hooks.cpp":
+            text = open(os.path.join(src_dir, f)).read()
+            assert "getenv" not in text, f"{f} reads the environment directly"
+    assert _lib.get_hook("VIS_SLOTS") == 8 and _lib.get_hook("EXCHANGE") == 0
+    monkeypatch.setenv("GGNN_VIS_SLOTS", "2")
+    monkeypatch.setenv("GGNN_EXCHANGE", "rccl")
+    assert _lib.get_hook("VIS_SLOTS") == 2 and _lib.get_hook("GGNN_EXCHANGE") == 1
+    monkeypatch.setenv("GGNN_TEST_HOOKS", "0")
+    assert _lib.get_hook("VIS_SLOTS") == 8 and _lib.get_hook("EXCHANGE") == 0   # env ignored
+    with _lib.hooks(VIS_SLOTS=4):
+        assert _lib.get_hook("VIS_SLOTS") == 4                                   # setter always counts
+    assert _lib.get_hook("VIS_SLOTS") == 8
+    monkeypatch.setenv("GGNN_TEST_HOOKS", "1")
+    with _lib.hooks(VIS_SLOTS=4):
+        assert _lib.get_hook("VIS_SLOTS") == 4                                   # setter beats env
+    assert _lib.get_hook("VIS_SLOTS") == 2
+    with pytest.raises(ValueError):
+        _lib.set_hook("NO_SUCH_HOOK", 1)
+    v = C.c_int64()
+    assert lib.ggnn_get_hook(b"NO_SUCH_HOOK", C.byref(v)) == 1
