@@ -81,6 +81,29 @@ def synthetic(kind, n, d, seed, device):
     raise ValueError(kind)
 
 
+def local_intrinsic_dimension(eng, base, args, k=20, sample=10_000, seed=97):
+    """Maximum-likelihood estimate of the local intrinsic dimension (Levina & Bickel 2004 in the
+    averaged-inverse form of MacKay & Ghahramani): for `sample` base points, the k exact nearest
+    neighbours (the engine's own brute force; the point itself, distance 0, is dropped) give
+    m(x) = [ 1/(k-1) * sum_{j<k} ln(T_k(x) / T_j(x)) ]^-1 ; reported: the inverse of the mean of
+    1/m(x).  Makes "SIFT1M-shaped" a number: published estimates for SIFT1M are around 20."""
+    g = torch.Generator(device=base.device)
+    g.manual_seed(seed)
+    idx = torch.randperm(base.shape[0], generator=g, device=base.device)[:sample]
+    pts = base[idx].contiguous()
+    _, d = eng.bf_query(pts, k + 1, _measure(args))
+    d = d.double()
+    if args.measure == "l2":
+        d = d.clamp_min(0).sqrt()
+    d = d[:, 1:]                       # drop the point itself
+    ok = d[:, 0] > 0                   # duplicates of the sample point carry no information
+    d = d[ok]
+    logs = torch.log(d[:, -1:] / d[:, :-1])
+    inv_m = logs.sum(1) / (k - 1)
+    return {"mle_k20": float(1.0 / inv_m.mean().item()), "points": int(ok.sum().item()),
+            "k": k, "estimator": "Levina-Bickel MLE, MacKay-Ghahramani averaging, exact neighbours"}
+
+
 def engine_clock_hz(device):
     """engine clock the device reports (kHz -> Hz); SQ cycle counters tick once per 4 clocks"""
     import ctypes as C
@@ -263,7 +286,7 @@ def measure_point(eng, query, gt, args, steps, tau=None, iters=None, warm=2):
 
 
 SEARCH_TAUS = (0.5, 0.64, 0.8, 0.9, 1.0, 1.2, 1.5, 2.0, 2.5)
-SEARCH_ITERS = (100, 175, 250, 400, 600, 1000, 1500, 2000)
+SEARCH_ITERS = (100, 175, 250, 400, 600, 800, 1000, 1500, 2000)
 
 
 def cheapest_point_at_recall(eng, query, gt, args, target=0.99):
@@ -291,7 +314,7 @@ def cheapest_point_at_recall(eng, query, gt, args, target=0.99):
     return best, top, tried
 
 
-def recall_target_sweep(args, device, ggnn, own_eng, own_query, own_gt):
+def recall_target_sweep(args, device, ggnn, own_eng, own_base, own_query, own_gt):
     """queries/s at recall@10 >= 0.99 per synthetic base (16 / 24 / 32-dimensional latent with
     integer values, and the 16-dimensional one with genuinely fractional float32 values, whose
     pre-screen codes are lossy), each with its own graph, exact ground truth and operating point"""
@@ -311,6 +334,8 @@ def recall_target_sweep(args, device, ggnn, own_eng, own_query, own_gt):
             build_s = eng.last_timing_ms()["build_ms"] / 1000.0
             gt, _ = eng.bf_query(query, args.k, _measure(args))
         r = {"same_settings_as_headline": measure_point(eng, query, gt, args, 3)}
+        r["local_intrinsic_dimension"] = local_intrinsic_dimension(
+            eng, own_base if kind == args.dataset else base, args)
         if build_s is not None:
             r["graph_build_s"] = build_s
         best, top, tried = cheapest_point_at_recall(eng, query, gt, args)
@@ -687,6 +712,7 @@ def run_single(args, device, ggnn):
         "traffic": pmc_traffic(args, False),
         "results": "bit-identical to the pre-screened run"})
 
+    lid = local_intrinsic_dimension(eng, base, args)
     out = {
         "metric": "queries/sec @ recall@10 (SIFT1M-shaped, k=10)",
         "value": value, "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
@@ -694,6 +720,7 @@ def run_single(args, device, ggnn):
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload_string(args), "parallelism": "single GPU"},
         "recall_at_10": recall, "recall_at_10_heldout_queries": recall_heldout, "c_at_1": c1,
+        "base_local_intrinsic_dimension": lid,
         "graph_build_s": build_kernel_s, "graph_build_wall_s": build_wall_s,
         "bf_query_ms": bf_ms,
         "bf_query": bf_block(args, bf_ms, bf_rescanned),
@@ -716,7 +743,7 @@ def run_single(args, device, ggnn):
                     "the grid that reaches it (query-kernel time, 10k-query blocking launches); "
                     "`same_settings_as_headline` is the headline's own (tau, iterations) on that "
                     "base.  The headline dataset is the easiest of these.",
-            "results": recall_target_sweep(args, device, ggnn, eng, query, gt)}
+            "results": recall_target_sweep(args, device, ggnn, eng, base, query, gt)}
         # the reference's own four SIFT1M settings (sift1m_fvecs.py:19-30 / ggnn_benchmark.cpp:
         # 196-200: tau 0.34 / 0.41 / 0.51 at 200 iterations, 0.64 at 400) on this synthetic base
         pts = {}

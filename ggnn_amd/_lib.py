@@ -57,6 +57,19 @@ _u32, _u64, _f32, _int, _vp, _sz = C.c_uint32, C.c_uint64, C.c_float, C.c_int, C
 _cfgp = C.POINTER(GraphConfig)
 
 # name -> (restype, argtypes); must list every function declared in include/ggnn_c.h
+class KernelWork(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("points", C.c_uint64), ("n_dist", C.c_uint64),
+                ("float_rows", C.c_uint64), ("code_rows", C.c_uint64), ("pops", C.c_uint64),
+                ("ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class BuildWork(C.Structure):
+    _fields_ = [("merge", KernelWork), ("sym", KernelWork)]
+
+
 SIGNATURES = {
     "ggnn_create": (_int, [C.POINTER(_vp)]),
     "ggnn_destroy": (None, [_vp]),
@@ -88,6 +101,7 @@ SIGNATURES = {
     "ggnn_get_shard_layout": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "ggnn_last_query_rows_read": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "ggnn_device_clock_hz": (_int, [_int, C.POINTER(C.c_double)]),
+    "ggnn_last_build_work": (_int, [_vp, C.POINTER(BuildWork)]),
     "ggnn_set_hook": (_int, [C.c_char_p, C.c_int64]),
     "ggnn_reset_hook": (_int, [C.c_char_p]),
     "ggnn_get_hook": (_int, [C.c_char_p, C.POINTER(C.c_int64)]),
@@ -170,7 +184,7 @@ def get_hook(name):
 
 
 class hooks:
-    """with hooks(VIS_SLOTS=1, QUERY_PAIRED=0): ...  -- set for the block, reset afterwards"""
+    """with hooks(VIS_SLOTS=1, BF_SLICES=7): ...  -- set for the block, reset afterwards"""
 
     def __init__(self, **values):
         self.values = values

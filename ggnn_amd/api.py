@@ -407,6 +407,13 @@ class GGNN:
     def set_collect_counters(self, enable=True):
         self._check(lib().ggnn_set_collect_counters(self._h, int(bool(enable))))
 
+    def last_build_work(self):
+        """work counters and kernel times of the merge / sym launches of the last build()
+        (set_collect_counters(True) before the build): {"merge": {...}, "sym": {...}}"""
+        w = _lib.BuildWork()
+        self._check(lib().ggnn_last_build_work(self._h, C.byref(w)))
+        return {"merge": w.merge.as_dict(), "sym": w.sym.as_dict()}
+
     def set_prescreen(self, enable=True):
         """Exact pre-screen of float32/Euclidean queries on an 8-bit copy of the base (an
         extension: same results, less memory traffic; costs N x D bytes per shard)."""

@@ -36,8 +36,6 @@
 //   preceded by KP > K rows of its own slice in exact (distance, index) order: nothing to check.
 #include <cstdlib>
 
-#include <mutex>
-
 #include "bf_common.hpp"
 #include "hooks.hpp"
 
@@ -1018,48 +1016,6 @@ bool bf_mfma_supported(const BfLaunch& a)
   return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
-// Per-call scratch comes from a PRIVATE stream-ordered pool per device (not the device's default
-// pool, whose settings belong to the rest of the process): freed blocks stay in it up to a
-// bounded amount, so repeated bf_query calls cost no allocation, and nothing else in the process
-// is affected.  Hook BF_POOL_KEEP_MB sets the amount kept (default 1024).  Creation is serialised:
-// two handles (or threads) may reach their first bf_query on one device at the same time.
-static hipMemPool_t scratch_pool()
-{
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-    return nullptr;
-  static std::mutex mtx;
-  static hipMemPool_t pools[64] = {};
-  static bool tried[64] = {};
-  std::lock_guard<std::mutex> lock(mtx);
-  if (!tried[dev]) {
-    tried[dev] = true;
-    hipMemPoolProps props{};
-    props.allocType = hipMemAllocationTypePinned;
-    props.handleTypes = hipMemHandleTypeNone;
-    props.location.type = hipMemLocationTypeDevice;
-    props.location.id = dev;
-    hipMemPool_t pool = nullptr;
-    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
-      uint64_t keep = static_cast<uint64_t>(std::clamp<int64_t>(hook(kHookBfPoolKeepMb), 0, 1 << 20))
-                      << 20;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      pools[dev] = pool;
-    }
-    (void)hipGetLastError();
-  }
-  return pools[dev];
-}
-static void* scratch_alloc(size_t bytes, hipStream_t stream)
-{
-  void* p = nullptr;
-  if (hipMemPool_t pool = scratch_pool())
-    GGNN_HIP_CHECK(hipMallocFromPoolAsync(&p, bytes, pool, stream));
-  else
-    GGNN_HIP_CHECK(hipMallocAsync(&p, bytes, stream));
-  return p;
-}
-
 size_t bf_rescan_tmp_entries(const BfLaunch& a, uint32_t* slices_out);
 void launch_bf_rescan(const BfLaunch& a, const uint32_t* qlist, const uint32_t* qcount,
                       int32_t* tmp_ids, float* tmp_dists, hipStream_t stream);
@@ -1280,7 +1236,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   if (a.n_rescanned)
     GGNN_HIP_CHECK(hipMemcpyAsync(a.n_rescanned, flags + 1, sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, stream));
-  GGNN_HIP_CHECK(hipFreeAsync(scratch, stream));
+  scratch_free(scratch, stream);
 }
 
 }  // namespace ggnn_amd

@@ -187,6 +187,8 @@ struct MergeLaunch {
   const uint8_t* ps_codes{nullptr};
   const float* ps_params{nullptr};
   uint32_t ps_Dc{0};
+  // optional [N_btm x 4]: distance evaluations, float rows, code rows, pops per point
+  uint32_t* n_work{nullptr};
 };
 void launch_merge(const MergeLaunch& a, hipStream_t stream);
 
@@ -207,6 +209,8 @@ struct SymLaunch {
   const uint8_t* ps_codes{nullptr};
   const float* ps_params{nullptr};
   uint32_t ps_Dc{0};
+  // optional [N_layer x 4]: distance evaluations, float rows, code rows, pops per point
+  uint32_t* n_work{nullptr};
 };
 void launch_sym(const SymLaunch& a, hipStream_t stream);
 
@@ -244,6 +248,10 @@ void launch_merge_results_range(uint32_t Nq, uint32_t k, uint32_t num_parts, uin
                                 const float* parts_dists, int32_t* ids_out, float* dists_out,
                                 const uint32_t* qlist, const uint32_t* qcount, uint32_t first,
                                 uint32_t count, hipStream_t stream, size_t part_elems = 0);
+
+// stream-ordered scratch of one launch from a private, bounded pool per device (scratch.cpp)
+void* scratch_alloc(size_t bytes, hipStream_t stream);
+void scratch_free(void* p, hipStream_t stream);
 
 // host layout math (graph_config.cpp)
 void graph_config_init(uint32_t N, uint32_t D, uint32_t KBuild, ggnn_graph_config* out);

@@ -18,6 +18,7 @@
 #include <fstream>
 #include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -408,6 +409,8 @@ struct ggnn_handle {
   // tracing
   float build_ms{0.f}, query_ms{0.f}, bf_ms{0.f};
   uint64_t last_n_dist{0}, last_n_pop{0}, last_float_rows{0}, last_code_rows{0};
+  ggnn_build_work build_work{};  // collect_counters during build(): see ggnn_last_build_work
+  std::mutex build_work_mutex;   // one host thread per GPU accounts into it
   uint32_t last_bf_rescanned{0};
 
   std::string last_error;
@@ -637,6 +640,41 @@ struct ggnn_handle {
         sym_atomic(static_cast<size_t>(N) * 4), stats_scratch(3 * kStatsBlocks * 4);
     ctx.build_ms = 0.f;
     uint64_t rng_calls = static_cast<uint64_t>(ctx.first_shard) << 16;
+    // diagnostic mode (collect_counters): per-point work counters and an own HIP-event time of
+    // every merge / sym launch, summed into build_work (ggnn_last_build_work)
+    DeviceBuffer work;
+    std::vector<uint32_t> h_work;
+    hipEvent_t wev_a = nullptr, wev_b = nullptr;
+    if (collect_counters) {
+      work.alloc(static_cast<size_t>(N) * 16);
+      h_work.resize(static_cast<size_t>(N) * 4);
+      GGNN_HIP_CHECK(hipEventCreate(&wev_a));
+      GGNN_HIP_CHECK(hipEventCreate(&wev_b));
+    }
+    struct EventGuard {
+      hipEvent_t &a, &b;
+      ~EventGuard()
+      {
+        if (a)
+          (void)hipEventDestroy(a);
+        if (b)
+          (void)hipEventDestroy(b);
+      }
+    } event_guard{wev_a, wev_b};
+    auto account = [&](ggnn_kernel_work& kw, uint32_t points, float ms) {
+      GGNN_HIP_CHECK(hipMemcpy(h_work.data(), work.p, static_cast<size_t>(points) * 16,
+                               hipMemcpyDeviceToHost));
+      std::lock_guard<std::mutex> lock(build_work_mutex);
+      kw.launches += 1;
+      kw.points += points;
+      kw.ms += ms;
+      for (uint32_t i = 0; i < points; ++i) {
+        kw.n_dist += h_work[4 * i];
+        kw.float_rows += h_work[4 * i + 1];
+        kw.code_rows += h_work[4 * i + 2];
+        kw.pops += h_work[4 * i + 3];
+      }
+    };
 
     for (uint32_t si = 0; si < ctx.shards.size(); ++si) {
       // the pre-screen copy serves the merge kernel too (made outside the timed region: it
@@ -680,7 +718,14 @@ struct ggnn_handle {
             m.ps_params = sh.ps_params.as<float>();
             m.ps_Dc = prescreen_code_dim(pad_D);
           }
-          launch_merge(m, stream);
+          if (collect_counters) {
+            m.n_work = work.as<uint32_t>();
+            EventTimer t(stream, wev_a, wev_b);
+            launch_merge(m, stream);
+            account(build_work.merge, cfg.Ns[btm], t.stop());
+          }
+          else
+            launch_merge(m, stream);
           GGNN_HIP_CHECK(hipMemcpyAsync(layer_graph(btm), graph_buffer.p,
                                         static_cast<size_t>(cfg.Ns[btm]) * K * 4,
                                         hipMemcpyDeviceToDevice, stream));
@@ -741,6 +786,12 @@ struct ggnn_handle {
             launch_sym(s, stream);
           }
         }
+        else if (collect_counters) {
+          s.n_work = work.as<uint32_t>();
+          EventTimer t(stream, wev_a, wev_b);
+          launch_sym(s, stream);
+          account(build_work.sym, cfg.Ns[layer], t.stop());
+        }
         else
           launch_sym(s, stream);
         launch_sym_buffer_merge(K, cfg.Ns[layer], sym_buffer.as<int32_t>(),
@@ -778,6 +829,7 @@ struct ggnn_handle {
              ggnn_measure measure)
   {
     prepare(KBuild);
+    build_work = ggnn_build_work{};
     try {
       for_each_device(
           [&](DeviceCtx& ctx) { build_device(ctx, tau_build, refinement_iterations, measure); });
@@ -1655,6 +1707,15 @@ ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable)
 {
   GGNN_NEED_HANDLE(h);
   h->prescreen = enable != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_last_build_work(const ggnn_t* h, ggnn_build_work* out)
+{
+  GGNN_NEED_HANDLE(h);
+  if (!out)
+    return GGNN_INVALID_ARGUMENT;
+  *out = h->build_work;
   return GGNN_OK;
 }
 

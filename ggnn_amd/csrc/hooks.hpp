@@ -15,7 +15,7 @@ enum Hook {
   kHookSymPrescreen,    // SYM_PRESCREEN    -1 auto (rows >= 1 KB) | 0 | 1
   kHookShardOverlap,    // SHARD_OVERLAP    1 = resident shards searched concurrently
   kHookVisSlots,        // VIS_SLOTS        usable keys per bucket of the hashed visited set (1..8)
-  kHookQueryPaired,     // QUERY_PAIRED     -1 auto | 0 one search per wave | 1 two per wave
+  kHookVisTagSet,       // VIS_TAG_SET      0 = rings of 481..2016 keys scanned instead of the tag set
   kHookBfPoolKeepMb,    // BF_POOL_KEEP_MB  release threshold of the bf scratch pool
   kHookBfNoI8,          // BF_NO_I8         1 = uint8 bf_query through the float kernels
   kHookBfI8V1,          // BF_I8_V1         1 = LDS-list i8 kernel instead of the register-set one

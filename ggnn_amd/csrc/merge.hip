@@ -15,6 +15,7 @@ struct MergeArgs {
   int32_t* graph_buffer;
   float* nn1_dist_buffer;
   uint32_t* n_dist;
+  uint4* n_work;  // optional [N_btm]: distance evaluations, float rows, code rows, pops per point
   uint32_t D, KBuild, S, G, S0, S0_off, layer_top, layer_btm, sorted, N_btm;
   uint32_t Ns_off[kLayers], STs_off[kLayers];
   float tau;
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(kWave)
 
   SortedList<R, HB> sl;
   sl.init(K + 1, a.sorted, kMergeCache, xi, lds.known, static_cast<int>(a.vis_slots));
-  uint32_t cnt_dist = 0;
+  uint32_t cnt_dist = 0, cnt_pop = 0;
 
   {
     // get_top_seg_offset, merge_layer.cu:40-61
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(kWave)
       const int anchor = sl.pop(sl.criteria(), lds.known);
       if (anchor == kEmptyKey)
         break;
+      ++cnt_pop;
       const int32_t* row = layer_graph + static_cast<size_t>(static_cast<uint32_t>(anchor)) * K;
       for (uint32_t j = 0; j < K; j += kKBlock) {
         const bool in_row = lane < (int)kKBlock && j + lane < K;
@@ -173,6 +175,8 @@ __global__ void __launch_bounds__(kWave)
   }
   if (lane == 0 && a.n_dist)
     a.n_dist[un] = cnt_dist;
+  if (lane == 0 && a.n_work)
+    a.n_work[un] = make_uint4(cnt_dist, rows_read.x, rows_read.y, cnt_pop);
 }
 
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
@@ -231,6 +235,7 @@ void launch_merge(const MergeLaunch& a, hipStream_t stream)
   args.graph_buffer = a.graph_buffer;
   args.nn1_dist_buffer = a.nn1_dist_buffer;
   args.n_dist = a.n_dist;
+  args.n_work = reinterpret_cast<uint4*>(a.n_work);
   args.D = c.D;
   args.KBuild = c.KBuild;
   args.S = c.S;

@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(kWave) __attribute__((
 query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  const WaveLds lds(lds_raw, a.cache);
+  // tag-set form: the visited ring is not in LDS, the candidate scratch follows the sorted keys
+  const WaveLds lds(lds_raw, is_tag_set(HB) ? a.sorted : a.cache);
   const int lane = threadIdx.x;
   const uint32_t n = block_linear_index();
   if (n >= a.Nq)
@@ -45,7 +46,11 @@ query_kernel(const QueryArgs a)
   load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
   SortedList<R, HB> sl;
-  sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots));
+  if constexpr (is_tag_set(HB))
+    sl.init_tagged(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots),
+                   a.ring + static_cast<size_t>(n) * (a.cache - a.sorted));
+  else
+    sl.init(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots));
 
   uint32_t cnt_dist = 0, cnt_pop = 0;
   uint2 cnt_rows = make_uint2(0u, 0u);
@@ -203,7 +208,14 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   // no register for it at 7 waves per SIMD -- measured 2.73 vs 2.54 ms with the spills)
   const bool fits = PSC::enabled || NCH == 1;
   const uint32_t hb = (sorted <= 64 && fits) ? vis_hash_regs(args.cache - sorted) : 0;
-  if (hb == 1)
+  // long rings (searches of 1000-2000 iterations): tag set + ring in global memory (traversal.hpp)
+  if (hb == 0 && sorted <= 64 && fits && args.ring && args.tag_bits == 8)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -8>), grid_for(args.Nq),
+                       dim3(kWave), tag_set_lds_bytes(sorted, args.cache - sorted), stream, args);
+  else if (hb == 0 && sorted <= 64 && fits && args.ring && args.tag_bits == 9)
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -9>), grid_for(args.Nq),
+                       dim3(kWave), tag_set_lds_bytes(sorted, args.cache - sorted), stream, args);
+  else if (hb == 1)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.Nq), dim3(kWave),
                        wave_lds_bytes(args.cache, 1), stream, args);
   else if (hb == 2)
@@ -273,8 +285,6 @@ static void launch_query_cfg(const QueryArgs& args, bool use_ps, ggnn_measure me
     launch_query_r<BaseT, LPR, NCH, kCos, NoPrescreen>(args, args.sorted, stream);
 }
 
-constexpr uint32_t kPairedMinQueries = 7 * 1024;
-
 void launch_query(const QueryLaunch& a, hipStream_t stream)
 {
   if (a.Nq == 0)
@@ -304,6 +314,22 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.on_gpu_shard = a.on_gpu_shard;
   args.tau = a.tau_query;
   args.vis_slots = vis_slots_hook();
+  // long rings: per-query visited rings as stream-ordered scratch of this launch
+  const uint32_t vis = args.cache - args.sorted;
+  if (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0) {
+    args.tag_bits = tag_set_bucket_bits(vis);
+    args.ring = static_cast<int32_t*>(
+        scratch_alloc(static_cast<size_t>(a.Nq) * vis * sizeof(int32_t), stream));
+  }
+  struct RingGuard {
+    void* p;
+    hipStream_t s;
+    ~RingGuard()
+    {
+      if (p)
+        scratch_free(p, s);
+    }
+  } ring_guard{args.ring, stream};
   const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
     GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(a.D), GGNN_INVALID_ARGUMENT,
@@ -314,19 +340,6 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
     args.ps_codes = a.ps_codes;
     args.ps_params = a.ps_params;
     args.ps_Dc = a.ps_Dc;
-  }
-
-  // Two searches per wave (query_x2.hip) where that form is instantiated: hook QUERY_PAIRED forces
-  // it on / off, otherwise by batch size -- up to 7 x 1024 queries every one-search wave is
-  // resident at once and more waves mean more parallelism; above that the paired form keeps the
-  // whole batch in ONE resident round (10 240 searches) and gives every SIMD more independent work.
-  {
-    const int64_t paired = hook(kHookQueryPaired);
-    const bool want = paired >= 0 ? paired == 1 : a.Nq > kPairedMinQueries;
-    if (want && launch_query_x2(args, a.dtype, a.measure, use_ps, stream)) {
-      GGNN_HIP_CHECK(hipGetLastError());
-      return;
-    }
   }
 
 #define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)

@@ -1,4 +1,4 @@
-// Kernel arguments of the query kernels (query.hip, query_x2.hip).
+// Kernel arguments of the query kernels (query.hip).
 #pragma once
 #include "common.hpp"
 
@@ -23,11 +23,10 @@ struct QueryArgs {
   const float* ps_params;
   uint32_t ps_Dc;
   uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
+  // tag-set form (long rings, traversal.hpp kTagSet): [Nq x (cache - sorted)] visited rings in
+  // global memory (scratch of the launch) and the bucket bits of the set
+  int32_t* ring;
+  uint32_t tag_bits;
 };
-
-// query_x2.hip: two searches per wave, phase-interleaved (see the file header).  Returns false when
-// the configuration has no paired instantiation (the caller then launches the one-search kernel).
-bool launch_query_x2(const QueryArgs& args, ggnn_dtype dtype, ggnn_measure measure, bool use_ps,
-                     hipStream_t stream);
 
 }  // namespace ggnn_amd

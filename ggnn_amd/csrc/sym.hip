@@ -14,6 +14,7 @@ struct SymArgs {
   const float* nn1_stats;
   int32_t* sym_buffer;   // [N_layer x KF]
   uint32_t* sym_atomic;  // [N_layer]
+  uint4* n_work;  // optional [N_layer]: distance evaluations, float rows, code rows, pops per point
   uint32_t D, KBuild, N_layer, sorted, first_n, count;
   float tau;
   // optional pre-screen copy of the base coded for this measure (prescreen.hip); float32 only
@@ -129,7 +130,7 @@ GGNN_DEV void sym_distances(SortedList<R>& sl, const SE& se, const WaveLds& lds,
 // half point is -- the criteria only tightens during a fetch -- so its float row is not read.
 template <int MODE, int R, class SE, class PS>
 GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int cand,
-                        const int32_t* translation, float criteria_half, const PS& ps)
+                        const int32_t* translation, float criteria_half, const PS& ps, uint4& work)
 {
   const int lane = threadIdx.x;
   cand = lower_half_to_both(cand);
@@ -143,15 +144,18 @@ GGNN_DEV void sym_fetch(SortedList<R>& sl, const SE& se, const WaveLds& lds, int
     lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
   __syncthreads();
   int nsurv_eval = nsurv;
+  work.x += nsurv;
   if constexpr (PS::enabled) {
     const float s_thr = ps.threshold(sl.dist_at(0) + sl.xi);
     if (s_thr < inf_f()) {
       nsurv_eval = prescreen_pass(ps, lds, nsurv, s_thr, translation);
+      work.z += nsurv;
       if (nsurv_eval == 0)
         return;
       __syncthreads();
     }
   }
+  work.y += nsurv_eval;
   sym_distances<MODE, R>(sl, se, lds, nsurv_eval, translation, criteria_half);
 }
 
@@ -248,6 +252,7 @@ __global__ void __launch_bounds__(kWave)
 
   SortedList<R> sl;
   sl.init(KF, a.sorted, kSymCache, xi, lds.known);
+  uint4 work = make_uint4(0u, 0u, 0u, 0u);
 
   for (uint32_t i = 0; i < KL; i += kKBlock) {
     // s_sym_ids, sym_query_layer.cu:67-75
@@ -260,6 +265,8 @@ __global__ void __launch_bounds__(kWave)
       const int other_m = a.translation ? a.translation[other_n] : other_n;
       float dq, dh;
       se.template set_half<MODE>(other_m, dq, dh);
+      ++work.x;  // the start point's own row
+      ++work.y;
       const float criteria_half = dh + xi;
       sl.reset(lds.known);
 #pragma unroll
@@ -276,6 +283,7 @@ __global__ void __launch_bounds__(kWave)
         const int anchor = sl.pop(sl.dist_at(0) + sl.xi, lds.known);
         if (anchor == kEmptyKey)
           break;
+        ++work.w;
         // neighbours at the anchor + its pending inverse links, sym_query_layer.cu:96-119
         for (uint32_t i2 = 0; i2 < K; i2 += kKBlock) {
           const uint32_t k2 = i2 + lane;
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(kWave)
             found = true;
             break;
           }
-          sym_fetch<MODE>(sl, se, lds, other_id, a.translation, criteria_half, ps);
+          sym_fetch<MODE>(sl, se, lds, other_id, a.translation, criteria_half, ps, work);
         }
       }
 
@@ -313,6 +321,8 @@ __global__ void __launch_bounds__(kWave)
       }
     }
   }
+  if (lane == 0 && a.n_work)
+    a.n_work[un] = work;
 }
 
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
@@ -358,6 +368,7 @@ void launch_sym(const SymLaunch& a, hipStream_t stream)
   args.nn1_stats = a.nn1_stats;
   args.sym_buffer = a.sym_buffer;
   args.sym_atomic = a.sym_atomic;
+  args.n_work = reinterpret_cast<uint4*>(a.n_work);
   args.D = a.D;
   args.KBuild = a.KBuild;
   args.N_layer = a.N_layer;

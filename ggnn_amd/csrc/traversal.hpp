@@ -140,10 +140,53 @@ inline size_t wave_lds_bytes(uint32_t cache, uint32_t hash_regs = 0)
   return (cache + WaveLds::extra_ints + hash_ints) * sizeof(int);
 }
 // bucket registers of the hashed visited set for a visited ring of `vis` entries: ~3 keys per
-// bucket on average when the ring is full; 0 = rings too long for it (the filter scans the ring)
+// bucket on average when the ring is full; 0 = rings too long for it (see the tag set below)
 inline uint32_t vis_hash_regs(uint32_t vis)
 {
   return vis <= 192 ? 1u : vis <= 480 ? 2u : 0u;
+}
+
+// ---- long rings (992 / 2016 keys: searches of 1000-2000 iterations) -----------------------------
+// SortedList<1, -nb_bits>.  A scan of the ring costs ~0.75 VALU instructions per key and candidate
+// group (768 per fetch on a full 992-key ring, twice the rest of a pop) and 32-bit buckets for such
+// a ring cost 8-25 KB of LDS per wave, i.e. the occupancy a search this long lives on.  Here
+//   * the ring itself is in GLOBAL memory (one store per pop, never read unless the ring wraps or
+//     the set overflows -- both rare), and
+//   * the set keeps 16-bit TAGS: with M = nb_bits + 16 >= bits(N_base - 1), k -> (k * C) mod 2^M
+//     (C odd) is a bijection on the keys, so (bucket = its top nb_bits, tag = its low 16 bits)
+//     identifies the key EXACTLY -- no false positives, 2 bytes per key: 256 buckets x 8 tags =
+//     4 KB for a 992-key ring.  Buckets fill from slot 0 and a byte per bucket counts the slots in
+//     use (tags are never removed), the probe masks the others.
+// A full bucket sends the key to the stash as before; a stash overflow, or the first wrap of the
+// ring, switches to the scan of the global ring for the rest of the search (exact in every case).
+// HB = -nb_bits selects the tag set with 2^nb_bits buckets (a compile-time constant: the table
+// offsets and the hash mask fold into immediates instead of living in scalar registers)
+constexpr bool is_tag_set(int hb)
+{
+  return hb < 0;
+}
+constexpr uint32_t kTagMul = 0x9E3779B1u;
+// buckets (log2) for a ring of `vis` keys: load factor <= 0.5 with 8 tags per bucket
+inline uint32_t tag_set_bucket_bits(uint32_t vis)
+{
+  uint32_t b = 5;
+  while ((8u << b) < 2 * vis)
+    ++b;
+  return b;
+}
+// usable when every key of the shard fits into nb_bits + 16 bits
+inline bool tag_set_usable(uint32_t vis, uint32_t n_base)
+{
+  if (vis < 481 || vis > 2016)
+    return false;
+  const uint32_t m = tag_set_bucket_bits(vis) + 16;
+  return m >= 32 || (static_cast<uint64_t>(n_base) <= (1ull << m));
+}
+// LDS of one wave: known[sorted] | candidate scratch | tags | counts | stash
+inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
+{
+  const size_t nb = size_t{1} << tag_set_bucket_bits(vis);
+  return (sorted + WaveLds::extra_ints + kVisStash) * sizeof(int) + nb * 16 + nb;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,6 +223,15 @@ struct SortedList {
   int slots;                  // usable keys per bucket (kVisSlots; tests shrink it)
   int* hbuckets;
   int* hstash;
+  // tag set (HB < 0) only
+  static constexpr bool kTag = is_tag_set(HB);
+  static constexpr int nb_bits = kTag ? -HB : 0;
+  int* ring_g;                // [VIS] visited ring of this search in global memory
+  // [2^nb_bits] tags in use per bucket, behind the tags
+  GGNN_DEV unsigned char* tcnt() const
+  {
+    return reinterpret_cast<unsigned char*>(hbuckets + (4 << nb_bits));
+  }
 
   GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* known,
                      int usable_slots = kVisSlots)
@@ -194,11 +246,36 @@ struct SortedList {
     hstash = hbuckets + NB * kVisSlots;
     reset(known);
   }
+  // tag-set form: only known[0, sorted) lives in LDS (WaveLds(base, sorted)); the ring is ring
+  GGNN_DEV void init_tagged(int best, int sorted, int cache, float xi_, int* known, int usable_slots,
+                            int* ring)
+  {
+    BEST = best;
+    SORTED = sorted;
+    P = sorted - best;
+    VIS = cache - sorted;
+    xi = xi_;
+    slots = usable_slots;
+    ring_g = ring;
+    hbuckets = known + sorted + static_cast<int>(WaveLds::extra_ints);  // tags, 4 ints per bucket
+    hstash = hbuckets + (4 << nb_bits) + ((1 << nb_bits) >> 2);
+    reset(known);
+  }
   // visited ring (and its hashed mirror) empty, simple_knn_cache.cuh:73-87
   GGNN_DEV void clear_visited(int* known)
   {
     vis_head = 0;
     vis_count = 0;
+    if constexpr (kTag) {
+      // counts to zero; tags need no clearing (masked by the counts), the global ring is only
+      // ever read below vis_count
+      int* c = reinterpret_cast<int*>(tcnt());
+      for (int i = threadIdx.x; i < ((1 << nb_bits) >> 2); i += kWave)
+        c[i] = 0;
+      stash_n = 0;
+      scan_mode = 0;
+      return;
+    }
     for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
       known[i] = kEmptyKey;
     if constexpr (HB > 0) {
@@ -294,6 +371,41 @@ struct SortedList {
       }
     }
     __syncthreads();
+  }
+
+  // tag set: bucket / tag of a key (see "long rings" above)
+  GGNN_DEV uint32_t tag_hash(uint32_t k) const
+  {
+    const uint32_t h = k * kTagMul;
+    return nb_bits + 16 >= 32 ? h : (h & ((1u << (nb_bits + 16)) - 1u));
+  }
+  // k: wave-uniform key that has just entered the visited ring
+  GGNN_DEV void tag_insert(int k)
+  {
+    const uint32_t h = tag_hash(static_cast<uint32_t>(k));
+    const uint32_t b = h >> 16;
+    const int c = uni(tcnt()[b]);
+    // A key can be popped more than once (quirk Q1 duplicates a queue entry when the ring of the
+    // priority queue has wrapped): the set keeps it once, or its copies would fill their bucket
+    const int lane = threadIdx.x;
+    const unsigned short mine =
+        reinterpret_cast<const unsigned short*>(hbuckets)[b * kVisSlots + (lane & (kVisSlots - 1))];
+    if (__any(lane < c && mine == static_cast<unsigned short>(h & 0xffffu)))
+      return;
+    if (c < slots) {
+      if (threadIdx.x == 0) {
+        reinterpret_cast<unsigned short*>(hbuckets)[b * kVisSlots + c] =
+            static_cast<unsigned short>(h & 0xffffu);
+        tcnt()[b] = static_cast<unsigned char>(c + 1);
+      }
+    }
+    else if (stash_n < kVisStash) {
+      if (threadIdx.x == 0)
+        hstash[stash_n] = k;
+      ++stash_n;
+    }
+    else
+      scan_mode = 1;
   }
 
   GGNN_DEV float dist_at(int i) const
@@ -440,7 +552,15 @@ struct SortedList {
         vis_insert(k0);
       }
     }
-    if (threadIdx.x == 0)
+    if constexpr (kTag) {
+      if (vis_count == VIS)
+        scan_mode = 1;  // the ring wraps (tags are never removed): the ring scan takes over
+      if (!scan_mode)
+        tag_insert(k0);
+      if (threadIdx.x == 0)
+        ring_g[vis_head] = k0;
+    }
+    else if (threadIdx.x == 0)
       known[SORTED + vis_head] = k0;
     vis_head = (vis_head + 1 >= VIS) ? 0 : vis_head + 1;
     vis_count = (vis_count + 1 > VIS) ? VIS : vis_count + 1;
@@ -514,8 +634,8 @@ struct SortedList {
     }
     __syncthreads();
     // with the hashed set only the sorted part is scanned; the visited ring is one bucket read
-    const bool hashed = (HB > 0) && !scan_mode;
-    const int E = hashed ? SORTED : SORTED + vis_count;
+    const bool hashed = (HB != 0) && !scan_mode;
+    const int E = (hashed || kTag) ? SORTED : SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
     // min over (entry XOR cand) is 0 iff some entry equals cand.  Pure VALU on purpose: the
@@ -527,6 +647,51 @@ struct SortedList {
       return min(min(acc, static_cast<unsigned>(e.z) ^ c), static_cast<unsigned>(e.w) ^ c);
     };
     unsigned acc0 = 0xffffffffu, acc1 = 0xffffffffu;
+    if constexpr (kTag) {
+      if (hashed) {
+        // lower half-wave: candidate j probes its bucket (8 tags = one 16-byte read, slots in use
+        // from the count byte); upper half-wave: the stash
+        const uint32_t hh = tag_hash(c);
+        const uint32_t b = hh >> 16;
+        const uint32_t tt = (hh & 0xffffu) * 0x10001u;
+        if (h == 0) {
+          const int4 w = *reinterpret_cast<const int4*>(hbuckets + b * 4);
+          const int v = tcnt()[b];
+          auto pair = [tt, v](unsigned a, int wv, int slot) {
+            const unsigned x = static_cast<unsigned>(wv) ^ tt;
+            const unsigned lo = slot < v ? (x & 0xffffu) : 1u;
+            const unsigned hi = slot + 1 < v ? (x >> 16) : 1u;
+            return min(a, min(lo, hi));
+          };
+          acc1 = pair(pair(pair(pair(acc1, w.x, 0), w.y, 2), w.z, 4), w.w, 6);
+        }
+        else {
+          for (int t = 0; t < stash_n; ++t)
+            acc1 = min(acc1, static_cast<unsigned>(hstash[t]) ^ c);
+        }
+      }
+      else {
+        // rare: the ring in global memory is scanned, 16 bytes per lane and step, both half-waves.
+        // The keys were stored by lane 0 of this wave and another lane's
+        // store does not update the vector L1: it is invalidated first (agent-scope acquire)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int4* rp = reinterpret_cast<const int4*>(ring_g);
+        const int steps = (vis_count + 3) >> 2;  // the ring length is a multiple of four
+        // (one step in flight: more would cost the whole kernel registers for a path that runs
+        // for the last few pops of a search, if at all)
+        for (int t = h; t < steps; t += 2) {
+          int4 e = rp[t];
+          if (t * 4 + 1 >= vis_count)
+            e.y = kEmptyKey;
+          if (t * 4 + 2 >= vis_count)
+            e.z = kEmptyKey;
+          if (t * 4 + 3 >= vis_count)
+            e.w = kEmptyKey;
+          acc1 = fold(acc1, e);
+        }
+      }
+    }
     if constexpr (HB > 0) {
       if (hashed) {
         // lanes j and j+32 hold candidate j: each reads one half of its bucket
@@ -859,16 +1024,15 @@ struct StepsOf {
 
 // Computes the distances of the nsurv compacted candidates in lds.ckeys[0,nsurv) and leaves
 // them in lds.cd0[0,nsurv).  Out-of-range chunks are neither loaded nor accumulated.
-// first: candidates [0, first) have been evaluated by the caller already (query_x2.hip).
 template <int MODE, class DE, int STEPS = StepsOf<DE::LPR, DE::NCH>::value>
 GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
-                                const int32_t* translation, int first = 0)
+                                const int32_t* translation)
 {
   constexpr int ROWS = DE::ROWS;
   using Chunk = typename DE::Chunk;
   const int lane = threadIdx.x;
   const int grp = lane / DE::LPR;
-  for (int s0 = first; s0 < nsurv; s0 += ROWS * STEPS) {
+  for (int s0 = 0; s0 < nsurv; s0 += ROWS * STEPS) {
     Chunk v[STEPS][DE::NCH];
     int rr[STEPS];
 #pragma unroll

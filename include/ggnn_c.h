@@ -165,6 +165,25 @@ ggnn_status ggnn_set_collect_counters(ggnn_t* h, int enable);
 /* rows the last ggnn_query read for those evaluations (needs collect_counters): float rows
  * (4*D bytes each) and, with the pre-screen, 8-bit code rows (prescreen_code_dim(D) bytes each: a power of two up to 64, multiples of 64 above). */
 ggnn_status ggnn_last_query_rows_read(const ggnn_t* h, uint64_t* float_rows, uint64_t* code_rows);
+/* Work of the construction kernels of the last ggnn_build, summed over every launch and shard
+ * (needs ggnn_set_collect_counters before the build; the build then synchronises after every
+ * merge / sym launch to time it with its own HIP events and to read the per-point counters, so it
+ * is a diagnostic mode).  For SURVEY 8(d)'s build roofline ("sum over kernel launches"):
+ * bytes of a kernel = float_rows x 4D + code_rows x prescreen_code_dim(D) + pops x graph-row bytes
+ * (merge: KBuild x 4; sym: (KBuild + KBuild/2) x 4: graph row + pending inverse links)
+ * + points x (own row 4D + result row). */
+typedef struct {
+  uint64_t launches, points;   /* kernel launches and points (= waves) they processed */
+  uint64_t n_dist;             /* distance evaluations of the reference's algorithm */
+  uint64_t float_rows;         /* 4D-byte rows actually read */
+  uint64_t code_rows;          /* pre-screen code rows read */
+  uint64_t pops;               /* graph rows read */
+  double ms;                   /* sum of the launches' HIP-event durations */
+} ggnn_kernel_work;
+typedef struct {
+  ggnn_kernel_work merge, sym;
+} ggnn_build_work;
+ggnn_status ggnn_last_build_work(const ggnn_t* h, ggnn_build_work* out);
 /* Exact pre-screen of the float32 query and merge kernels (no reference counterpart; results
  * are identical with it on or off, see ggnn_op_prescreen_encode).  On by default; hook PRESCREEN = 0
  * (ggnn_set_hook) turns the default of handles created afterwards off. */
@@ -204,8 +223,8 @@ void ggnn_set_log_level(int level);
  *   SHARD_OVERLAP       1     0 = resident shards of one GPU searched one launch at a time
  *   VIS_SLOTS           8     usable keys per bucket of the hashed visited set, 1..8 (small values
  *                             exercise stash, overflow and removal paths)
- *   QUERY_PAIRED       -1     query kernel form: -1 auto (by batch size) | 0 one search per wave
- *                             | 1 two searches per wave (query_x2.hip) wherever it is instantiated
+ *   VIS_TAG_SET         1     0 = visited rings of 481..2016 keys (searches of 513..2048 iterations)
+ *                             are scanned instead of probed through the 16-bit tag set
  *   BF_POOL_KEEP_MB  1024     bytes the private bf_query scratch pool keeps between calls
  *   BF_NO_I8            0     1 = uint8 bf_query through the float matrix-core kernels
  *   BF_I8_V1            0     1 = LDS-list i8 kernel instead of the register-set one

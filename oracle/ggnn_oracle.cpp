@@ -32,6 +32,13 @@ double g_margin_min = std::numeric_limits<double>::infinity();
 // bench baseline only: plain 8-accumulator loops instead of the thread/tree emulation
 // (identical results on integer-valued data, where every summation order is exact)
 int g_fast_distance = 0;
+// 0: the reference's summation order (thread-strided partials + cub::BlockReduce, restated);
+// 1: the summation order of the product kernels' DistEngine (ggnn_amd/csrc/traversal.hpp:
+//    LPR lanes per row, NCH 16-byte chunks per lane, fmaf chains per lane, pairwise tree over
+//    the lanes) -- with it float results of query / merge / top can be compared BIT FOR BIT,
+//    which separates "same algorithm" from "same rounding" (the reference's own order is not
+//    pinned by anything, see the file header)
+int g_wave_order = 0;
 std::atomic<uint64_t> g_accept_total{0};
 std::atomic<uint64_t> g_eval_total{0};
 
@@ -119,6 +126,28 @@ struct BaseView {
 // ------------------------------------------------------------------------------------------
 // Row A: Distance  (include/ggnn/cuda_utils/distance.cuh:34-164)
 // ------------------------------------------------------------------------------------------
+  // DistEngine's order (traversal.hpp:696-860, pick_dist_config): lane g of LPR owns the 16-byte
+  // chunks c*LPR + g, c < NCH, accumulated in (c, element) order; lanes are summed pairwise
+  // (quad_perm, row_half_mirror, row_mirror, permlane16/32 swaps = a balanced tree in lane order)
+void wave_layout(int dtype, uint32_t D, uint32_t& lpr, uint32_t& nch, uint32_t& epc)
+  {
+    epc = dtype == ORC_F32 ? 4 : 16;
+    const uint32_t chunks = (D + epc - 1) / epc;
+    if (chunks <= 8) { lpr = 8; nch = 1; }
+    else if (chunks <= 16) { lpr = 8; nch = 2; }
+    else if (chunks <= 32) { lpr = 16; nch = 2; }
+    else if (chunks <= 64) { lpr = 16; nch = 4; }
+    else if (chunks <= 256) { lpr = 64; nch = 4; }
+    else { lpr = 64; nch = 16; }
+  }
+float tree_sum(float* v, uint32_t n)
+  {
+    for (uint32_t w = 1; w < n; w <<= 1)
+      for (uint32_t i = 0; i + w < n; i += 2 * w)
+        v[i] = v[i] + v[i + w];
+    return v[0];
+  }
+
 struct DistCalc {
   BaseView base;
   int measure;
@@ -150,6 +179,8 @@ struct DistCalc {
         pa[t] = acc;
       }
       q_norm = block_reduce_sum(pa.data(), block);
+      if (g_wave_order)
+        q_norm = wave_query_norm();
     }
   }
 
@@ -193,9 +224,85 @@ struct DistCalc {
     return norm_sqr > 0.f ? std::fabs(1.0f - a / std::sqrt(norm_sqr)) : 1.0f;
   }
 
+  float wave_query_norm() const
+  {
+    uint32_t lpr, nch, epc;
+    wave_layout(base.dtype, base.D, lpr, nch, epc);
+    float lane[64];
+    for (uint32_t g = 0; g < lpr; ++g) {
+      float nrm = 0.f;
+      for (uint32_t c = 0; c < nch; ++c)
+        for (uint32_t e = 0; e < epc; ++e) {
+          const uint32_t d = (c * lpr + g) * epc + e;
+          const float v = d < base.D ? q[d] : 0.f;
+          nrm = fmaf(v, v, nrm);
+        }
+      lane[g] = nrm;
+    }
+    return tree_sum(lane, lpr);
+  }
+  float distance_wave(uint64_t other) const
+  {
+    uint32_t lpr, nch, epc;
+    wave_layout(base.dtype, base.D, lpr, nch, epc);
+    const uint32_t D = base.D;
+    float la[64], lb[64];
+    for (uint32_t g = 0; g < lpr; ++g) {
+      if (base.dtype == ORC_U8) {
+        // packed integer arithmetic (v_dot4_u32_u8), exact per lane
+        uint32_t ab = 0, bb = 0, qq = 0;
+        for (uint32_t c = 0; c < nch; ++c)
+          for (uint32_t e = 0; e < epc; ++e) {
+            const uint32_t d = (c * lpr + g) * epc + e;
+            if (d < D) {
+              const uint32_t o = static_cast<uint32_t>(base.at(other, d));
+              const uint32_t qv = static_cast<uint32_t>(q[d]);
+              ab += o * qv;
+              bb += o * o;
+              qq += qv * qv;
+            }
+          }
+        if (measure == ORC_EUCLIDEAN) {
+          la[g] = static_cast<float>((qq + bb) - 2u * ab);
+          lb[g] = 0.f;
+        }
+        else {
+          la[g] = static_cast<float>(ab);
+          lb[g] = static_cast<float>(bb);
+        }
+        continue;
+      }
+      float a = 0.f, b = 0.f;
+      for (uint32_t c = 0; c < nch; ++c)
+        for (uint32_t e = 0; e < epc; ++e) {
+          const uint32_t d = (c * lpr + g) * epc + e;
+          const float o = d < D ? base.at(other, d) : 0.f;
+          const float qq = d < D ? q[d] : 0.f;
+          if (measure == ORC_EUCLIDEAN) {
+            const float diff = o - qq;
+            a = fmaf(diff, diff, a);
+          }
+          else {
+            a = fmaf(o, qq, a);
+            b = fmaf(o, o, b);
+          }
+        }
+      la[g] = a;
+      lb[g] = b;
+    }
+    const float a = tree_sum(la, lpr);
+    if (measure == ORC_EUCLIDEAN)
+      return a;
+    const float nrm = tree_sum(lb, lpr);
+    const float norm_sqr = q_norm * nrm;
+    return norm_sqr > 0.f ? std::fabs(1.0f - a / std::sqrt(norm_sqr)) : 1.0f;
+  }
+
   float distance(uint64_t other)
   {
     ++n_calls;
+    if (g_wave_order)
+      return distance_wave(other);
     if (g_fast_distance)
       return distance_fast(other);
     const uint32_t D = base.D;
@@ -526,12 +633,73 @@ struct SymDist {
       }
       q_norm = block_reduce_sum(pa.data(), block);
       half_norm = block_reduce_sum(pb.data(), block);
+      if (g_wave_order) {
+        // SymEngine::set_half, ggnn_amd/csrc/sym.hip: per-lane fmaf chains + lane tree
+        uint32_t lpr, nch, epc;
+        wave_layout(base.dtype, base.D, lpr, nch, epc);
+        float la[64], lb[64];
+        for (uint32_t g = 0; g < lpr; ++g) {
+          float a = 0.f, b = 0.f;
+          for (uint32_t c = 0; c < nch; ++c)
+            for (uint32_t e = 0; e < epc; ++e) {
+              const uint32_t d = (c * lpr + g) * epc + e;
+              const float qq = d < base.D ? q[d] : 0.f;
+              const float hh = d < base.D ? half[d] : 0.f;
+              a = fmaf(qq, qq, a);
+              b = fmaf(hh, hh, b);
+            }
+          la[g] = a;
+          lb[g] = b;
+        }
+        q_norm = tree_sum(la, lpr);
+        half_norm = tree_sum(lb, lpr);
+      }
     }
   }
   // :214-283
   void distance(uint64_t other, float& d_query, float& d_half)
   {
     const uint32_t D = base.D;
+    if (g_wave_order) {
+      // SymEngine::partial2 + finish, ggnn_amd/csrc/sym.hip
+      uint32_t lpr, nch, epc;
+      wave_layout(base.dtype, D, lpr, nch, epc);
+      float la[64], lb[64], lc[64];
+      for (uint32_t g = 0; g < lpr; ++g) {
+        float a = 0.f, b = 0.f, n = 0.f;
+        for (uint32_t c = 0; c < nch; ++c)
+          for (uint32_t e = 0; e < epc; ++e) {
+            const uint32_t d = (c * lpr + g) * epc + e;
+            const float o = d < D ? base.at(other, d) : 0.f;
+            const float qq = d < D ? q[d] : 0.f;
+            const float hh = d < D ? half[d] : 0.f;
+            if (measure == ORC_EUCLIDEAN) {
+              const float dq = qq - o;
+              a = fmaf(dq, dq, a);
+              const float dh = hh - o;
+              b = fmaf(dh, dh, b);
+            }
+            else {
+              a = fmaf(qq, o, a);
+              b = fmaf(hh, o, b);
+              n = fmaf(o, o, n);
+            }
+          }
+        la[g] = a;
+        lb[g] = b;
+        lc[g] = n;
+      }
+      d_query = tree_sum(la, lpr);
+      d_half = tree_sum(lb, lpr);
+      if (measure == ORC_COSINE) {
+        const float n = tree_sum(lc, lpr);
+        const float qn = n * q_norm;
+        const float hn = n * half_norm;
+        d_query = qn > 0.f ? std::fabs(1.0f - d_query / std::sqrt(qn)) : 1.0f;
+        d_half = hn > 0.f ? std::fabs(1.0f - d_half / std::sqrt(hn)) : 1.0f;
+      }
+      return;
+    }
     for (uint32_t t = 0; t < block; ++t) {
       float a = 0.f, b = 0.f, n = 0.f;
       for (uint32_t item = 0; item < items; ++item) {
@@ -587,6 +755,10 @@ inline uint32_t radix_key(float f)
 
 extern "C" {
 
+void orc_set_wave_order(int enable)
+{
+  g_wave_order = enable;
+}
 void orc_set_fast_distance(int enable)
 {
   g_fast_distance = enable;

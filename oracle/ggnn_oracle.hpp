@@ -147,6 +147,9 @@ void orc_wave_model_script(uint32_t BEST, uint32_t SORTED, uint32_t CACHE, float
 // bench cpu_baseline only: compute distances with plain multi-accumulator loops (a fair scalar/
 // SIMD port) instead of the thread-by-thread emulation.  Default off (parity tests).
 void orc_set_fast_distance(int enable);
+// float distances of query / merge / top summed in the order of the product kernels' DistEngine
+// instead of the reference's (restated) cub::BlockReduce order; see g_wave_order
+void orc_set_wave_order(int enable);
 // statistics: number of distance evaluations accepted (d < criteria) by orc_query since reset
 uint64_t orc_accept_total(int reset);
 // statistics: number of distance evaluations of orc_query / orc_merge since reset

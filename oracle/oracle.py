@@ -345,6 +345,21 @@ def op_transform():
     return (3, 0, 0)
 
 
+def set_wave_order(enable):
+    """float sums in the product kernels' order (bit-for-bit comparisons on float data) instead
+    of the reference's restated cub::BlockReduce order"""
+    lib().orc_set_wave_order(int(bool(enable)))
+
+
+class wave_order:
+    def __enter__(self):
+        set_wave_order(True)
+
+    def __exit__(self, *exc):
+        set_wave_order(False)
+        return False
+
+
 def set_fast_distance(enable):
     lib().orc_set_fast_distance(int(bool(enable)))
 

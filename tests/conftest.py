@@ -25,6 +25,15 @@ def orc():
     return oracle
 
 
+@pytest.fixture(autouse=True)
+def _oracle_modes_reset():
+    """a test that switches the oracle's float summation order never leaks it into the next one"""
+    yield
+    mod = sys.modules.get("oracle.oracle")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod.set_wave_order(False)
+
+
 def make_int_data(N, D, seed):
     """S-int of SURVEY 8(d): integers in [0,255] stored as f32 -> every fp32 sum is exact."""
     return np.random.default_rng(seed).integers(0, 256, (N, D)).astype(np.float32)

@@ -103,14 +103,15 @@ def test_gist1m_shape_cosine_960(orc):
         assert float(dd[gt[n].long()].max()) <= float(best[K - 1]) + 1e-6
         np.testing.assert_allclose(gt_d[n].cpu().numpy(), best.cpu().numpy(), atol=2e-6)
     del b64, bn
-    # oracle traversal on the GPU-built graph, statistically (float cosine on both sides)
+    # oracle traversal on the GPU-built graph with the kernels' float summation order: every
+    # decision of the cosine search is then the same decision on both sides -- bit for bit
     g = eng.get_graph(0)
-    o_ids, o_d = orc.query(base.cpu().numpy(), query[:64].cpu().numpy(), g.graph[0].view.numpy(),
-                           g.translation[3].view.numpy().reshape(-1),
-                           g.nn1_stats.view.numpy().reshape(-1), K, 1.0, 400, 1)
-    same = ids[:64].cpu().numpy() == o_ids
-    assert same.mean() > 0.95
-    np.testing.assert_allclose(d[:64].cpu().numpy()[same], o_d[same], rtol=1e-3, atol=1e-6)
+    with orc.wave_order():
+        o_ids, o_d = orc.query(base.cpu().numpy(), query[:64].cpu().numpy(), g.graph[0].view.numpy(),
+                               g.translation[3].view.numpy().reshape(-1),
+                               g.nn1_stats.view.numpy().reshape(-1), K, 1.0, 400, 1)
+    assert np.array_equal(ids[:64].cpu().numpy(), o_ids)
+    assert np.array_equal(d[:64].cpu().numpy(), o_d)
 
 
 def test_uint8_shard_beyond_4gib():
