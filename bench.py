@@ -114,13 +114,14 @@ def engine_clock_hz(device):
 
 
 KERNEL_SOURCES = ("traversal.hpp", "query.hip", "common.hpp", "prescreen.hip")
+BUILD_SOURCES = ("traversal.hpp", "merge.hip", "sym.hip", "common.hpp", "prescreen.hip")
 
 
-def kernel_source_sha():
+def kernel_source_sha(sources=None):
     """fingerprint of the traversal kernel sources: committed counter summaries carry the one
     they were collected with and are ignored once it no longer matches"""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in (sources or KERNEL_SOURCES):
         with open(os.path.join(ROOT, "ggnn_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -216,6 +217,7 @@ def _latest_profile(suffix, args):
         if doc.get("workload") == workload_string(args):
             doc["_file"] = os.path.relpath(f, ROOT)
             doc["_stale"] = doc.get("kernel_source_sha") != kernel_source_sha()
+            doc["_stale_build"] = doc.get("build_source_sha") != kernel_source_sha(BUILD_SOURCES)
             return doc
     return None
 
@@ -395,55 +397,75 @@ def sift1m_real(directory, ggnn, device):
     return out
 
 
-def build_roofline(args, eng, base):
-    """merge kernel (75 % of the build): the final (3 -> 0) launch replayed on the built graph
-    through the operator seam with work counters; bytes by SURVEY 8(d)'s per-kernel formula."""
-    import ctypes as C
-    from ggnn_amd import _lib, ops
-    from ggnn_amd._lib import check, lib
-    view = _lib.GraphView()
-    check(lib().ggnn_get_graph(eng._h, 0, C.byref(view)))
-    cfg = view.config
-    N, K, D = cfg.Ns[0], cfg.KBuild, args.dim
-    dev = base.device
-    gb = torch.empty((N, K), dtype=torch.int32, device=dev)
-    nn1 = torch.zeros(N, device=dev)
-    nd = torch.zeros(N, dtype=torch.int32, device=dev)
-    out = {}
-    ps = ops.prescreen_encode(base)
-    for label, pre in (("plain", None), ("prescreened", ps)):
-        ms = []
-        for rep in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            if pre is None:
-                check(lib().ggnn_op_merge(base.data_ptr(), 0, 0, cfg, view.graph, view.translation,
-                                          view.selection, view.nn1_stats, args.tau_build, 3, 0,
-                                          gb.data_ptr(), nn1.data_ptr(), nd.data_ptr(),
-                                          torch.cuda.current_stream().cuda_stream))
-            else:
-                check(lib().ggnn_op_merge_prescreened(
-                    base.data_ptr(), pre[0].data_ptr(), pre[1].data_ptr(), 0, cfg, view.graph,
-                    view.translation, view.selection, view.nn1_stats, args.tau_build, 3, 0,
-                    gb.data_ptr(), nn1.data_ptr(), nd.data_ptr(),
-                    torch.cuda.current_stream().cuda_stream))
-            e1.record()
-            torch.cuda.synchronize()
-            if rep:
-                ms.append(e0.elapsed_time(e1))
-        t = float(np.mean(ms)) * 1e-3
-        n_dist = int(nd.sum().item())
-        # every evaluation reads one 4D-byte row in the reference's algorithm; graph rows and
-        # translation entries are < 2 % and left out
-        ref_bytes = n_dist * D * 4
-        out[label] = {"ms": t * 1e3, "n_dist_per_point": n_dist / N, "points_per_s": N / t,
-                      "reference_algorithm_GBs": ref_bytes / t / 1e9,
-                      "frac_of_hbm_peak": ref_bytes / t / 1e9 / HBM_PEAK_GBS}
-    out["note"] = ("merge_kernel (3 -> 0) on the final graph of this run, 1M points; 'plain' reads "
-                   "a 4D-byte row per evaluation (rates above the HBM peak are L2 / Infinity-Cache "
-                   "hits: consecutive points share neighbourhoods); 'prescreened' is the kernel "
-                   "the build uses (same results, most rows replaced by D-byte code rows), its "
-                   "GB/s is the reference algorithm's bytes over its time = bytes avoided")
+L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md: aggregate L2 bandwidth, 8 XCDs
+
+
+def _pmc_kernel_total(args, needle):
+    """(bytes, launches) of FETCH_SIZE x2 + WRITE_SIZE summed over every launch of the kernels
+    whose name contains `needle`, from the committed PMC passes of this workload (else None)"""
+    doc = _latest_profile("_pmc_hbm.json", args)
+    if not doc or doc["_stale_build"]:
+        return None, None
+    total, launches = 0.0, 0
+    for name, c in doc["kernels"].items():
+        if needle in name and "FETCH_SIZE" in c:
+            n = c["FETCH_SIZE"]["launches"]
+            wr = c.get("WRITE_SIZE", {"avg_kb": 0.0})["avg_kb"]
+            total += n * (2.0 * c["FETCH_SIZE"]["avg_kb"] + wr) * 1024.0
+            launches += n
+    return (total, launches) if launches else (None, None)
+
+
+def build_roofline(args, ggnn, base):
+    """SURVEY 8(d) for the build: per construction kernel, summed over every launch of one whole
+    build -- own algorithmic bytes (live work counters of a second, counted build: rows actually
+    read, graph rows per pop, the point's own row and its result row), the sum of the launches'
+    HIP-event durations, the fraction of the 8 TB/s HBM peak, and the fabric traffic of the same
+    launches from the committed PMC passes.  The reference algorithm's bytes (n_dist x 4D: every
+    evaluation reads a float row) are a named secondary."""
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_collect_counters(True)
+    eng.build(args.k_build, args.tau_build, args.refine, _measure(args))
+    work = eng.last_build_work()
+    counted_build_s = eng.last_timing_ms()["build_ms"] / 1e3
+    del eng
+    d, k = args.dim, args.k_build
+    esz = 1 if args.dtype == "u8" else 4
+    code_dim = max(16, 1 << (d - 1).bit_length()) if d <= 64 else (d + 63) // 64 * 64
+    out = {"counted_build_s": counted_build_s,
+           "note": "one whole build (all layers and refinement passes) in the diagnostic mode that "
+                   "synchronises after every merge / sym launch; `achieved` can exceed what HBM "
+                   "delivers because consecutive points share neighbourhoods (rows served by the "
+                   "L2s and the Infinity Cache): `traffic` is what reached the fabric"}
+    for kname, w, row_bytes_per_pop, needle in (
+            ("merge_kernel", work["merge"], k * 4, "merge_kernel"),
+            ("sym_kernel", work["sym"], (k + k // 2) * 4, "sym_kernel")):
+        if not w["launches"]:
+            continue
+        own = (w["float_rows"] * d * esz + w["code_rows"] * code_dim + w["pops"] * row_bytes_per_pop
+               + w["points"] * (d * esz + k * 4))
+        ref = w["n_dist"] * d * esz + w["pops"] * row_bytes_per_pop + w["points"] * (d * esz + k * 4)
+        t = w["ms"] * 1e-3
+        traffic, launches = _pmc_kernel_total(args, needle)
+        if launches is not None and launches != w["launches"]:
+            traffic = None
+        gbs = own / t / 1e9
+        out[kname] = {
+            "launches": w["launches"], "points": w["points"], "kernel_ms_sum": w["ms"],
+            "n_dist": w["n_dist"], "float_rows": w["float_rows"], "code_rows": w["code_rows"],
+            "graph_rows": w["pops"],
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "bytes": own, "traffic": traffic,
+                         "traffic_over_algorithmic": None if traffic is None else traffic / own,
+                         "frac_of_l2_peak": gbs / L2_PEAK_GBS,
+                         "definition": "float_rows x D x s + code_rows x Dc + graph_rows x row bytes "
+                                       "+ points x (D x s + KBuild x 4), summed over the launches / "
+                                       "sum of their HIP-event durations / 8 TB/s"},
+            "reference_algorithm": {"bytes": ref, "achieved": ref / t / 1e9,
+                                    "note": "n_dist x D x s instead of the rows actually read: what "
+                                            "the reference's algorithm would move (bytes avoided by "
+                                            "the exact pre-screen when above `bytes`)"}}
     return out
 
 
@@ -734,7 +756,7 @@ def run_single(args, device, ggnn):
     }
     plain_f32_l2 = (args.dtype, args.measure) == ("f32", "l2")
     if not args.no_build_roofline and plain_f32_l2:
-        out["build"] = {"graph_build_s": build_kernel_s, "merge_kernel": build_roofline(args, eng, base)}
+        out["build"] = dict(build_roofline(args, ggnn, base), graph_build_s=build_kernel_s)
     if not args.no_datasets:
         out["recall_targets"] = {
             "target": "recall@10 >= 0.99 against each base's own exact bf_query",

@@ -74,7 +74,25 @@ __device__ __forceinline__ uint32_t block_linear_index()
 {
   return blockIdx.y * gridDim.x + blockIdx.x;
 }
+// XCD-aware block -> item mapping for kernels whose consecutive items share data (the construction
+// kernels: consecutive points share their neighbourhoods).  Workgroup b runs on XCD b % 8 (observed,
+// MI355X_MICROARCH.md; only speed depends on it) and every XCD has its own L2: with the identity
+// mapping each XCD works on every 8th point and all eight L2s fetch the same rows.  Here XCD x gets
+// the CONTIGUOUS items [x * per, (x + 1) * per), per = ceil(n / 8); launch xcd_grid_blocks(n)
+// workgroups and drop the indices >= n.
+__device__ __forceinline__ uint32_t xcd_contiguous_index(uint32_t b, uint32_t n, bool enabled)
+{
+  if (!enabled)
+    return b;
+  const uint32_t per = (n + 7u) >> 3;
+  const uint32_t i = b >> 3;
+  return i < per ? (b & 7u) * per + i : 0xffffffffu;
+}
 #endif
+inline uint64_t xcd_grid_blocks(uint64_t n, bool enabled)
+{
+  return enabled ? ((n + 7) / 8) * 8 : n;
+}
 
 extern int g_log_level;
 #define GGNN_LOG(level, ...)                 \

@@ -24,6 +24,7 @@ struct MergeArgs {
   const float* ps_params;
   uint32_t ps_Dc;
   uint32_t vis_slots;  // usable keys per bucket of the hashed visited set (kVisSlots; test hook)
+  uint32_t xcd_map;    // XCD-aware block -> point mapping (common.hpp)
 };
 
 // occupancy target of the common instantiations (as for the query kernel): a tuning knob
@@ -42,13 +43,13 @@ uint32_t merge_sorted_size(uint32_t KBuild)
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
 __global__ void __launch_bounds__(kWave)
-    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_MERGE_WAVES : 1)))
+    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? GGNN_MERGE_WAVES : 1)))
     merge_kernel(const MergeArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kMergeCache);
   const int lane = threadIdx.x;
-  const uint32_t un = block_linear_index();
+  const uint32_t un = xcd_contiguous_index(block_linear_index(), a.N_btm, a.xcd_map != 0);
   if (un >= a.N_btm)
     return;
   const int n = static_cast<int>(un);
@@ -186,16 +187,16 @@ static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
   // visited ring of 192 entries mirrored in a hash set (traversal.hpp) where the registers allow
   // it at 7 waves per SIMD (see launch_query_r)
   if (args.sorted <= 64 && (PSC::enabled || NCH == 1))
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
                        wave_lds_bytes(kMergeCache, 1), stream, args);
   else if (args.sorted <= 64)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 256)
-    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(args.N_btm), dim3(kWave),
+    hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 4, MODE, PSC>), grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
                        lds, stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
@@ -252,6 +253,7 @@ void launch_merge(const MergeLaunch& a, hipStream_t stream)
   }
   args.tau = a.tau_build;
   args.vis_slots = vis_slots_hook();
+  args.xcd_map = (hook(kHookXcdMap) & 1) != 0;
   GGNN_REQUIRE(args.sorted < kMergeCache, GGNN_UNSUPPORTED, "KBuild too large for the merge cache");
   if (!args.N_btm)
     return;

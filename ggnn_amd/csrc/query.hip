@@ -22,7 +22,7 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
 __global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 2) ? GGNN_QUERY_WAVES : 1)))
+    amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? GGNN_QUERY_WAVES : 1)))
 query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -68,11 +68,15 @@ query_kernel(const QueryArgs a)
   // the row is there.  The load is issued from fetch()'s after-filter hook, i.e. after the wait
   // for this pop's own graph row -- issued before it, the two waits merge into one vmcnt(0).
   int spec_key = kEmptyKey, spec_row = kEmptyKey;
+#ifdef GGNN_PHASE_CYCLES
+  phase_begin();
+#endif
   for (uint32_t ite = 0; ite < a.max_iters; ++ite) {
     // query_layer.cu:58-63
     const float d0 = sl.dist_at(0);
     sl.xi = (MODE == kL2) ? fminf(xi, d0 * a.tau * a.tau) : fminf(xi, d0 * a.tau);
     const int anchor = sl.pop(sl.criteria(), lds.known);
+    GGNN_TICK(0);  // pop
     if (anchor == kEmptyKey)
       break;
     ++cnt_pop;
@@ -98,6 +102,9 @@ query_kernel(const QueryArgs a)
     }
   }
 
+#ifdef GGNN_PHASE_CYCLES
+  phase_end();
+#endif
   // write_best + dists, query_layer.cu:81-90 (EMPTY becomes -1 + offset, as in the reference)
   const size_t out_row = (static_cast<size_t>(n) * a.shards_per_gpu + a.on_gpu_shard) * a.KQuery;
   const int32_t id_offset = static_cast<int32_t>(a.on_gpu_shard * a.N_base);
@@ -216,8 +223,13 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -9>), grid_for(args.Nq),
                        dim3(kWave), tag_set_lds_bytes(sorted, args.cache - sorted), stream, args);
   else if (hb == 1)
+#ifdef GGNN_PHASE_CYCLES
+    hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.Nq), dim3(kWave),
+                       16384 + 256, stream, args);
+#else
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(args.Nq), dim3(kWave),
                        wave_lds_bytes(args.cache, 1), stream, args);
+#endif
   else if (hb == 2)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2>), grid_for(args.Nq), dim3(kWave),
                        wave_lds_bytes(args.cache, 2), stream, args);
@@ -347,5 +359,19 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
 #undef GGNN_LAUNCH_QUERY
   GGNN_HIP_CHECK(hipGetLastError());
 }
+
+#ifdef GGNN_PHASE_CYCLES
+extern "C" int ggnn_debug_phase_cycles(unsigned long long* out16, int reset)
+{
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_acc), 16 * sizeof(unsigned long long)) != hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_acc), z, sizeof(z)) != hipSuccess)
+      return 1;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace ggnn_amd

@@ -21,6 +21,7 @@ struct SymArgs {
   const uint8_t* ps_codes;
   const float* ps_params;
   uint32_t ps_Dc;
+  uint32_t xcd_map;  // XCD-aware block -> point mapping (common.hpp)
 };
 
 constexpr uint32_t kSymCache = 128;          // sym_query_layer.cuh:43
@@ -226,9 +227,10 @@ __global__ void __launch_bounds__(kWave)
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const WaveLds lds(lds_raw, kSymCache);
   const int lane = threadIdx.x;
-  if (block_linear_index() >= a.count)
+  const uint32_t bi = xcd_contiguous_index(block_linear_index(), a.count, a.xcd_map != 0);
+  if (bi >= a.count)
     return;
-  const uint32_t un = a.first_n + block_linear_index();
+  const uint32_t un = a.first_n + bi;
   if (un >= a.N_layer)
     return;
   const int n = static_cast<int>(un);
@@ -330,10 +332,10 @@ static void launch_sym_r(const SymArgs& args, hipStream_t stream)
 {
   const size_t lds = wave_lds_bytes(kSymCache);
   if (args.sorted <= 64)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(args.count), dim3(kWave),
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 1, MODE, PSC>), grid_for(xcd_grid_blocks(args.count, args.xcd_map != 0)), dim3(kWave),
                        lds, stream, args);
   else if (args.sorted <= 128)
-    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(args.count), dim3(kWave),
+    hipLaunchKernelGGL((sym_kernel<BaseT, LPR, NCH, 2, MODE, PSC>), grid_for(xcd_grid_blocks(args.count, args.xcd_map != 0)), dim3(kWave),
                        lds, stream, args);
   else
     throw Error(GGNN_UNSUPPORTED, "KBuild too large for the sym cache");
@@ -376,6 +378,7 @@ void launch_sym(const SymLaunch& a, hipStream_t stream)
   args.first_n = a.first_n;
   args.count = std::min(a.count, a.N_layer > a.first_n ? a.N_layer - a.first_n : 0u);
   args.tau = a.tau_build;
+  args.xcd_map = (hook(kHookXcdMap) & 2) != 0;
   GGNN_REQUIRE(args.sorted < kSymCache, GGNN_UNSUPPORTED, "KBuild too large for the sym cache");
   if (!args.count)
     return;

@@ -24,6 +24,45 @@ namespace ggnn_amd {
 
 #define GGNN_DEV __device__ __forceinline__
 
+// Stats build (-DGGNN_PHASE_CYCLES, scripts/phase_cycles.py): shader cycles per phase of a pop,
+// accumulated by lane 0 in LDS behind the first 16 KB of the workgroup's allocation and added to
+// g_phase_acc when the wave ends.  Every tick drains the memory counters first, so phases are
+// separated (and the kernel is slower than the product build).
+#ifdef GGNN_PHASE_CYCLES
+static __device__ unsigned long long g_phase_acc[16];
+GGNN_DEV void phase_tick(int i)
+{
+  extern __shared__ __attribute__((aligned(16))) int ph_lds[];
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(ph_lds + 4096);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    if (i >= 0)
+      p[1 + i] += t - p[0];
+    p[0] = t;
+  }
+}
+GGNN_DEV void phase_begin()
+{
+  extern __shared__ __attribute__((aligned(16))) int ph_lds[];
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(ph_lds + 4096);
+  if (threadIdx.x < 17)
+    p[threadIdx.x] = 0;
+  phase_tick(-1);
+}
+GGNN_DEV void phase_end()
+{
+  extern __shared__ __attribute__((aligned(16))) int ph_lds[];
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(ph_lds + 4096);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (threadIdx.x < 16)
+    atomicAdd(&g_phase_acc[threadIdx.x], p[1 + threadIdx.x]);
+}
+#define GGNN_TICK(i) phase_tick(i)
+#else
+#define GGNN_TICK(i) ((void)0)
+#endif
+
 GGNN_DEV int rdlane(int v, int l)
 {
   return __builtin_amdgcn_readlane(v, l);
@@ -1056,6 +1095,7 @@ GGNN_DEV void compute_distances(const DE& de, const WaveLds& lds, int nsurv,
           v[s][c] = ChunkOf<typename DE::Base>::zero();
       }
     }
+    GGNN_TICK(6);  // float rows arrived (issue + wait)
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (s0 + s * ROWS >= nsurv)
@@ -1302,6 +1342,7 @@ GGNN_DEV int prescreen_pass(const PS& ps, const WaveLds& lds, int nsurv, float s
       }
     }
     __syncthreads();  // all keys of this round are in registers before the in-place compaction
+    GGNN_TICK(4);     // code rows arrived (issue + wait)
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       if (s0 + s * ROWS >= nsurv)
@@ -1333,10 +1374,12 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
 {
   const int lane = threadIdx.x;
   cand = lower_half_to_both(cand);
+  GGNN_TICK(1);  // graph row arrived
   if (FILTER)
     cand = sl.filter(cand, lds.known);
   const unsigned long long surv = __ballot(lane < 32 && cand != kEmptyKey);
   const int nsurv = __popcll(surv);
+  GGNN_TICK(2);  // filter
   after_filter();
   if (nsurv == 0)
     return 0;
@@ -1345,22 +1388,28 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
     lds.ckeys[__popcll(surv & ((1ull << lane) - 1ull))] = cand;
   __syncthreads();
   int neval = nsurv;
+  GGNN_TICK(3);  // compaction
   if constexpr (PS::enabled) {
     const float s_thr = ps.threshold(sl.criteria());
     if (s_thr < inf_f()) {
       neval = prescreen_pass(ps, lds, nsurv, s_thr, translation);
       rows.y += nsurv;
+      GGNN_TICK(5);  // pre-screen verdicts + compaction
       if (neval == 0)
         return nsurv;
       __syncthreads();
     }
   }
   // after the pre-screen only a handful of candidates are left: fewer rows in flight, fewer VGPRs
+  // (three chunks per lane, 8 rows per load instruction: one step already has 8 rows in flight)
   constexpr int kSteps = StepsOf<DE::LPR, DE::NCH>::value;
-  compute_distances<MODE, DE, (PS::enabled && kSteps > 2) ? 2 : kSteps>(de, lds, neval,
-                                                                        translation);
+  constexpr int kExactSteps = !PS::enabled ? kSteps : (DE::NCH == 3 && DE::ROWS >= 8) ? 1
+                              : (kSteps > 2)                                         ? 2
+                                                                                     : kSteps;
+  compute_distances<MODE, DE, kExactSteps>(de, lds, neval, translation);
   rows.x += neval;
   __syncthreads();
+  GGNN_TICK(7);  // exact distances
   const float cd = lane < neval ? lds.cd0[lane] : inf_f();
   const int ck = lane < neval ? lds.ckeys[lane] : kEmptyKey;
   // criteria() never increases during a fetch, so candidates failing it now fail it later
@@ -1373,6 +1422,7 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
     if (d < sl.criteria())
       sl.push(k, d);
   }
+  GGNN_TICK(8);  // accept / push replay
   return nsurv;
 }
 template <int MODE, bool FILTER, class SL, class DE>
@@ -1403,6 +1453,11 @@ inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
     return {8, 1};
   if (chunks <= 16)
     return {8, 2};
+  // 17..24 chunks (D = 96 float32, the DEEP shape): 8 lanes x 3 chunks cover the row exactly; the
+  // {16, 2} layout would leave 8 of its 32 chunk slots -- a quarter of every load instruction --
+  // on dead lanes
+  if (chunks <= 24)
+    return {8, 3};
   if (chunks <= 32)
     return {16, 2};
   if (chunks <= 64)
@@ -1419,6 +1474,7 @@ inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
     if ((dtype) == GGNN_F32) {                                                    \
       if (_dc.lpr == 8 && _dc.nch == 1) { F(float, 8, 1); }                       \
       else if (_dc.lpr == 8 && _dc.nch == 2) { F(float, 8, 2); }                  \
+      else if (_dc.lpr == 8 && _dc.nch == 3) { F(float, 8, 3); }                  \
       else if (_dc.lpr == 16 && _dc.nch == 2) { F(float, 16, 2); }                \
       else if (_dc.lpr == 16 && _dc.nch == 4) { F(float, 16, 4); }                \
       else if (_dc.lpr == 64 && _dc.nch == 4) { F(float, 64, 4); }                \
@@ -1427,6 +1483,7 @@ inline DistConfig pick_dist_config(uint32_t D, ggnn_dtype dtype)
     else {                                                                        \
       if (_dc.lpr == 8 && _dc.nch == 1) { F(uint8_t, 8, 1); }                     \
       else if (_dc.lpr == 8 && _dc.nch == 2) { F(uint8_t, 8, 2); }                \
+      else if (_dc.lpr == 8 && _dc.nch == 3) { F(uint8_t, 8, 3); }                \
       else if (_dc.lpr == 16 && _dc.nch == 2) { F(uint8_t, 16, 2); }              \
       else if (_dc.lpr == 16 && _dc.nch == 4) { F(uint8_t, 16, 4); }              \
       else if (_dc.lpr == 64 && _dc.nch == 4) { F(uint8_t, 64, 4); }              \

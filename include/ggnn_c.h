@@ -225,6 +225,8 @@ void ggnn_set_log_level(int level);
  *                             exercise stash, overflow and removal paths)
  *   VIS_TAG_SET         1     0 = visited rings of 481..2016 keys (searches of 513..2048 iterations)
  *                             are scanned instead of probed through the 16-bit tag set
+ *   XCD_MAP             3     bit 0: merge kernel, bit 1: sym kernel -- workgroups of one XCD take a
+ *                             contiguous range of points (consecutive points share neighbourhoods)
  *   BF_POOL_KEEP_MB  1024     bytes the private bf_query scratch pool keeps between calls
  *   BF_NO_I8            0     1 = uint8 bf_query through the float matrix-core kernels
  *   BF_I8_V1            0     1 = LDS-list i8 kernel instead of the register-set one

@@ -135,6 +135,7 @@ void wave_layout(int dtype, uint32_t D, uint32_t& lpr, uint32_t& nch, uint32_t& 
     const uint32_t chunks = (D + epc - 1) / epc;
     if (chunks <= 8) { lpr = 8; nch = 1; }
     else if (chunks <= 16) { lpr = 8; nch = 2; }
+    else if (chunks <= 24) { lpr = 8; nch = 3; }
     else if (chunks <= 32) { lpr = 16; nch = 2; }
     else if (chunks <= 64) { lpr = 16; nch = 4; }
     else if (chunks <= 256) { lpr = 64; nch = 4; }

@@ -8,8 +8,9 @@ out_dir = "profiles"
 os.makedirs(out_dir, exist_ok=True)
 CMD = "python bench.py --lean" + (" " + extra if extra else "")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_source_sha  # noqa: E402  (fingerprint of the profiled kernel sources)
+from bench import kernel_source_sha, BUILD_SOURCES  # noqa: E402  (fingerprints of the profiled kernel sources)
 SHA = kernel_source_sha()
+BUILD_SHA = kernel_source_sha(BUILD_SOURCES)
 
 
 def counters(name):
@@ -47,7 +48,7 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter] = {"launches": len(v), "avg_kb": sum(v) / len(v),
                                           "last_kb": v[-1], "max_kb": max(v)}
-json.dump({"workload": workload, "kernel_source_sha": SHA,
+json.dump({"workload": workload, "kernel_source_sha": SHA, "build_source_sha": BUILD_SHA,
            "command": f"rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- {CMD} "
                       "--steps 3 --warmup 1 (one pass per counter)",
            "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 64 B per "

@@ -116,7 +116,13 @@ def test_bench_single_gpu_line_small():
         assert (at is None and "not_reached_best" in r) or at["recall_at_10"] >= 0.99, kind
     one = d["strong_scaling_one_gpu"]
     assert one["queries_per_s"] > 0 and "pipelined_batches" in one
-    assert d["build"]["merge_kernel"]["prescreened"]["ms"] > 0
+    for kname in ("merge_kernel", "sym_kernel"):
+        b = d["build"][kname]
+        assert b["launches"] > 0 and b["kernel_ms_sum"] > 0 and b["float_rows"] > 0
+        assert b["roofline"]["bound"] == "hbm" and b["roofline"]["frac"] > 0
+        assert b["roofline"]["bytes"] <= b["reference_algorithm"]["bytes"]
+    for kind, r in res.items():
+        assert 1.0 < r["local_intrinsic_dimension"]["mle_k20"] < 128.0, kind
 
 
 def test_sharded_engine_over_rccl_one_rank_world():
