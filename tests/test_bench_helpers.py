@@ -35,7 +35,7 @@ def test_committed_counter_passes_are_ignored_when_sources_changed(tmp_path, mon
             {"SQ_ACTIVE_INST_VALU": 6.0e8, "SQ_INSTS_VALU": 6.4e8,
              "FETCH_SIZE": {"avg_kb": 1000.0}, "WRITE_SIZE": {"avg_kb": 10.0}}}
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "aaaa")
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda sources=None: "aaaa")
     for suffix in ("_pmc_sq.json", "_pmc_hbm.json"):
         json.dump({"workload": bench.workload_string(args), "kernel_source_sha": "aaaa",
                    "kernels": kern}, open(prof / ("r99" + suffix), "w"))
@@ -43,7 +43,7 @@ def test_committed_counter_passes_are_ignored_when_sources_changed(tmp_path, mon
     assert note is None and c["SQ_ACTIVE_INST_VALU"] == 6.0e8 and f.endswith("r99_pmc_sq.json")
     assert bench.pmc_traffic(args, True) == 2 * 1000.0 * 1024 + 10.0 * 1024
     # the sources moved on: both are refused, with a reason
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "bbbb")
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda sources=None: "bbbb")
     c, f, note = bench.pmc_sq(args, True)
     assert c is None and "changed" in note
     assert bench.pmc_traffic(args, True) is None
