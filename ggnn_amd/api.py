@@ -407,6 +407,13 @@ class GGNN:
     def set_collect_counters(self, enable=True):
         self._check(lib().ggnn_set_collect_counters(self._h, int(bool(enable))))
 
+    def last_query_parts(self):
+        """half-batches the last blocking multi-GPU query() was searched in (2: the second half's
+        search overlapped the exchange and merge of the first)"""
+        n = C.c_uint32()
+        self._check(lib().ggnn_last_query_parts(self._h, C.byref(n)))
+        return int(n.value)
+
     def last_build_work(self):
         """work counters and kernel times of the merge / sym launches of the last build()
         (set_collect_counters(True) before the build): {"merge": {...}, "sym": {...}}"""

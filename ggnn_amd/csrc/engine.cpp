@@ -420,6 +420,7 @@ struct ggnn_handle {
   int rccl_state{0};  // 0 = not tried, 1 = communicators ready, -1 = unavailable (peer copies)
   uint32_t rccl_fallbacks{0};  // exchanges that failed inside RCCL and were served by peer copies
   const char* last_exchange{"none"};
+  uint32_t last_query_parts{1};  // half-batches the last blocking query was searched in
 
   ~ggnn_handle() { destroy_comms(); }
   void destroy_comms()
@@ -1077,6 +1078,23 @@ struct ggnn_handle {
     const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
     const size_t part = nq * row;
 
+    // Several GPUs: a blocking batch is searched as TWO half-batches in flight, so that the
+    // all-gather, the slice merges and the result copies of the first half overlap the search of
+    // the second (the step is latency-bound: one ~2 ms kernel per GPU, then the exchange) -- the
+    // caller gets the pipelining of query_async without having to use it.  Hook QUERY_SPLIT = 0
+    // switches it off, 1 forces it from 2 queries on (tests).
+    last_query_parts = 1;
+    {
+      const int64_t split = hook(kHookQuerySplit);
+      const bool several = devs.size() > 1 || hook(kHookExchange) == 1;
+      const bool want = split >= 0 ? split == 1 : nq >= 4096;
+      if (several && !direct && !collect_counters && want && nq >= 2) {
+        query_split(q, nq, D, dtype, loc, q_gpu, k_query, tau_query, max_iterations, measure,
+                    ids_out, dists_out);
+        return;
+      }
+    }
+
     constexpr int lane = DeviceCtx::kBlockingLane;
     for_each_device([&](DeviceCtx& ctx) {
       Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
@@ -1114,6 +1132,65 @@ struct ggnn_handle {
       return;
     }
     exchange(lane, nq, k_query, row, ids_out, dists_out, /*blocking=*/true);
+  }
+
+  // blocking multi-GPU query as two half-batches on the asynchronous lanes 0 and 1 (see query())
+  void query_split(const void* q, uint32_t nq, uint32_t D, ggnn_dtype dtype, ggnn_location loc,
+                   int q_gpu, uint32_t k_query, float tau_query, uint32_t max_iterations,
+                   ggnn_measure measure, int32_t* ids_out, float* dists_out)
+  {
+    const size_t row = static_cast<size_t>(k_query) * shards_per_gpu;
+    const size_t es = dtype_size(dtype);
+    const uint32_t first[2] = {0u, nq / 2};
+    const uint32_t count[2] = {nq / 2, nq - nq / 2};
+    std::vector<Staged> staged(devs.size());
+    // the whole query set once per GPU, both halves enqueued on their lanes; nothing waits yet
+    for (size_t g = 0; g < devs.size(); ++g) {
+      DeviceCtx& ctx = devs[g];
+      ctx.activate();
+      for (uint32_t si = 0; si < shards_per_gpu; ++si)
+        (void)ensure_prescreen(ctx, si, measure);
+      ctx.ensure_shard_streams();
+      staged[g] = stage_query(ctx, q, nq, D, dtype, loc, q_gpu);
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_ready, ctx.stream));
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_a, ctx.stream));
+      for (int half = 0; half < 2; ++half) {
+        if (!count[half])
+          continue;
+        const int lane = half;
+        hipStream_t st = ctx.lane_stream(lane);
+        GGNN_HIP_CHECK(hipStreamWaitEvent(st, ctx.ev_ready, 0));
+        DeviceCtx::ExchangeBufs& x = ctx.xb[lane];
+        if (&ctx != &devs[0] && devs[0].xb[lane].consumed)
+          GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[0].xb[lane].consumed, 0));
+        const size_t part = count[half] * row;
+        grow_lane(ctx, lane, x.r_pack, 2 * part * 4);
+        int32_t* r = x.r_pack.as<int32_t>();
+        const uint8_t* qh = static_cast<const uint8_t*>(staged[g].ptr) +
+                            static_cast<size_t>(first[half]) * pad_D * es;
+        enqueue_local_search(ctx, lane, qh, count[half], k_query, tau_query, max_iterations,
+                             measure, r, reinterpret_cast<float*>(r + part));
+        GGNN_HIP_CHECK(hipEventRecord(ctx.shard_done[lane], st));
+        GGNN_HIP_CHECK(hipStreamWaitEvent(ctx.stream, ctx.shard_done[lane], 0));
+      }
+      GGNN_HIP_CHECK(hipEventRecord(ctx.ev_b, ctx.stream));  // both halves searched on this GPU
+    }
+    // the first half is exchanged, merged and copied out while the second is still being searched
+    for (int half = 0; half < 2; ++half)
+      if (count[half])
+        exchange(half, count[half], k_query, row, ids_out + static_cast<size_t>(first[half]) * k_query,
+                 dists_out + static_cast<size_t>(first[half]) * k_query, /*blocking=*/true);
+    for (DeviceCtx& ctx : devs) {
+      ctx.activate();
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      float ms = 0.f;
+      GGNN_HIP_CHECK(hipEventElapsedTime(&ms, ctx.ev_a, ctx.ev_b));
+      ctx.query_ms = ms;
+      query_ms = std::max(query_ms, ms);
+      GGNN_LOG(0, "[GPU: %d] query parts %u..%u, two half-batches in flight => ms: %.3f [%u points "
+                  "query]", ctx.device, ctx.first_shard, ctx.first_shard + shards_per_gpu - 1, ms, nq);
+    }
+    last_query_parts = 2;
   }
 
   // Grows one exchange buffer of a lane.  Batches in flight on the lane may still use the old
@@ -1237,9 +1314,12 @@ struct ggnn_handle {
     }
     // fault injection (hook RCCL_FAIL_AFTER = n): the n-th exchange of the process reports an RCCL
     // failure before anything is enqueued -- the path a real failure takes from here on
-    if (const int64_t fail_at = hook(kHookRcclFailAfter); fail_at > 0) {
-      static std::atomic<int64_t> exchanges{0};
-      if (++exchanges == fail_at)
+    {
+      static std::atomic<int64_t> exchanges{0};  // counted while the hook is set
+      const int64_t fail_at = hook(kHookRcclFailAfter);
+      if (fail_at <= 0)
+        exchanges.store(0);
+      else if (++exchanges == fail_at)
         GGNN_RCCL_CHECK(ncclInternalError);
     }
     GGNN_RCCL_CHECK(rccl.GroupStart());
@@ -1707,6 +1787,15 @@ ggnn_status ggnn_set_prescreen(ggnn_t* h, int enable)
 {
   GGNN_NEED_HANDLE(h);
   h->prescreen = enable != 0;
+  return GGNN_OK;
+}
+
+ggnn_status ggnn_last_query_parts(const ggnn_t* h, uint32_t* parts)
+{
+  GGNN_NEED_HANDLE(h);
+  if (!parts)
+    return GGNN_INVALID_ARGUMENT;
+  *parts = h->last_query_parts;
   return GGNN_OK;
 }
 

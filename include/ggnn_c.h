@@ -158,6 +158,9 @@ ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t
  * over xGMI + per-GPU slice merge) or "copy" (peer copies to the first GPU: contexts sharing one
  * device, or no librccl).  Hook EXCHANGE (ggnn_set_hook) forces one of them. */
 const char* ggnn_last_exchange(const ggnn_t* h);
+/* number of half-batches the last blocking multi-GPU ggnn_query was searched in: 2 when the search
+ * of the second half overlapped the exchange and merge of the first (hook QUERY_SPLIT), else 1 */
+ggnn_status ggnn_last_query_parts(const ggnn_t* h, uint32_t* parts);
 /* queries of the last ggnn_bf_query that were answered by the exhaustive scan because the
  * matrix-core pre-selection could not be certified exact (tracing; results are exact either way) */
 ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned);
@@ -225,6 +228,8 @@ void ggnn_set_log_level(int level);
  *                             exercise stash, overflow and removal paths)
  *   VIS_TAG_SET         1     0 = visited rings of 481..2016 keys (searches of 513..2048 iterations)
  *                             are scanned instead of probed through the 16-bit tag set
+ *   QUERY_SPLIT        -1     blocking ggnn_query on several GPUs as two half-batches in flight:
+ *                             -1 auto (from 4096 queries) | 0 never | 1 always (from 2 queries)
  *   XCD_MAP             3     bit 0: merge kernel, bit 1: sym kernel -- workgroups of one XCD take a
  *                             contiguous range of points (consecutive points share neighbourhoods)
  *   BF_POOL_KEEP_MB  1024     bytes the private bf_query scratch pool keeps between calls

@@ -607,3 +607,71 @@ def test_query_async_growing_batches_on_one_slot():
     eng.synchronize()
     for n, t, w in zip(sizes, tickets, want):
         assert torch.equal(t.ids.cpu(), w[0]) and torch.equal(t.dists.cpu(), w[1]), n
+
+
+@pytest.mark.gpu
+def test_blocking_multi_gpu_query_is_split_in_two_half_batches():
+    """Several GPUs: a blocking query() runs as two half-batches in flight (the exchange and merge
+    of the first overlap the search of the second) -- on by default from 4096 queries, forced here
+    from 2 (hook QUERY_SPLIT).  Results are bit-identical to the unsplit call, on the copy path
+    (two contexts on device 0) and on the RCCL path (one-rank world), odd query counts included."""
+    import ggnn_amd as ggnn
+    from ggnn_amd import _lib
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 487), make_int_data(777, D, 488)
+    for gpus, exchange, how in (([0, 0], 0, "copy"), ([0], 1, "rccl")):
+        eng = ggnn.GGNN()
+        eng.set_base(base)
+        eng.set_gpus(gpus)
+        eng.set_shard_size(2000)
+        eng.build(24, 0.5, 1)
+        with _lib.hooks(EXCHANGE=exchange, QUERY_SPLIT=0):
+            ref = eng.query(q, K, 0.7, 200)
+            assert eng.last_query_parts() == 1 and eng.last_exchange() == how
+        with _lib.hooks(EXCHANGE=exchange, QUERY_SPLIT=1):
+            for nq in (777, 2, 3, 64):
+                ids, d = eng.query(q[:nq], K, 0.7, 200)
+                assert eng.last_query_parts() == 2 and eng.last_exchange() == how
+                assert torch.equal(ids, ref[0][:nq]) and torch.equal(d, ref[1][:nq]), (how, nq)
+            assert eng.last_timing_ms()["query_ms"] > 0
+        # default: small batches are not split, large ones are
+        with _lib.hooks(EXCHANGE=exchange):
+            eng.query(q, K, 0.7, 200)
+            assert eng.last_query_parts() == 1
+            big = np.concatenate([q] * 6)[:4200]
+            ids, d = eng.query(big, K, 0.7, 200)
+            assert eng.last_query_parts() == 2
+            assert torch.equal(ids[:777], ref[0]) and torch.equal(d[777:1554], ref[1])
+        del eng
+
+
+@pytest.mark.gpu
+def test_rccl_failure_falls_back_to_peer_copies():
+    """Fault injection (hook RCCL_FAIL_AFTER): the n-th exchange reports an RCCL failure.  The engine
+    drains its streams, drops the communicators for good and serves that call and every later one
+    through peer copies -- same results, blocking and asynchronous."""
+    import ggnn_amd as ggnn
+    from ggnn_amd import _lib
+    N, D, K = 8000, 64, 10
+    base, q = make_int_data(N, D, 587), make_int_data(333, D, 588)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_gpus([0])
+    eng.set_shard_size(2000)
+    eng.build(24, 0.5, 1)
+    ref = eng.query(q, K, 0.7, 200)
+    with _lib.hooks(EXCHANGE=1, QUERY_SPLIT=0):
+        a = eng.query(q, K, 0.7, 200)
+        assert eng.last_exchange() == "rccl"
+        qd = torch.from_numpy(q).cuda()
+        t0 = eng.query_async(qd, K, 0.7, 200, slot=1)     # in flight on the communicators
+        with _lib.hooks(RCCL_FAIL_AFTER=1):                # the next exchange fails inside RCCL
+            b = eng.query(q, K, 0.7, 200)
+        assert eng.last_exchange() == "copy"
+        eng.synchronize()
+        c = eng.query(q, K, 0.7, 200)                      # communicators are gone for good
+        assert eng.last_exchange() == "copy"
+        t1 = eng.query_async(qd, K, 0.7, 200, slot=2)
+        eng.synchronize()
+    for ids, d in (a, b, c, (t0.ids.cpu(), t0.dists.cpu()), (t1.ids.cpu(), t1.dists.cpu())):
+        assert torch.equal(ids, ref[0]) and torch.equal(d, ref[1])
