@@ -835,19 +835,33 @@ def sharded_case(args, device, world, rank, spg, cpu_group):
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ids, dists = step()
-        kernel_ms.append(eng.last_timing_ms()["query_ms"])
     barrier()
     elapsed, = max_over_ranks(time.perf_counter() - t0)
+    blocking_parts = sharded.last_query_parts
+    # the same steps as ONE batch each (the blocking mode of rounds 1-3; also the source of the
+    # kernel time: the half-batches of the split run on the asynchronous lanes, which are not timed)
+    sharded.split_blocking = False
+    kernel_ms = []
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(3, args.steps // 4)):
+        ids_u, dists_u = step()
+        kernel_ms.append(eng.last_timing_ms()["query_ms"])
+    barrier()
+    elapsed_unsplit, = max_over_ranks((time.perf_counter() - t0) / max(3, args.steps // 4))
+    if not (torch.equal(ids_u, ids) and torch.equal(dists_u, dists)):
+        raise RuntimeError("split and unsplit blocking query results differ")
     # work counters of one pass (untimed) for the aggregate roofline figure: bytes the kernels
     # of all ranks read by their own accounting / the slowest rank's kernel time / N x 8 TB/s
     eng.set_collect_counters(True)
     step()
     cnt, rows = eng.last_query_counters(), eng.last_query_rows_read()
     eng.set_collect_counters(False)
+    sharded.split_blocking = None
     kms = float(np.mean(kernel_ms))
     tot = torch.tensor([cnt["n_dist"], cnt["n_pop"], rows["float_rows"], rows["code_rows"]],
                        dtype=torch.float64)
@@ -872,6 +886,10 @@ def sharded_case(args, device, world, rank, spg, cpu_group):
     out = {"n_base_per_shard": args.n_base, "shards_per_gpu": spg, "roofline": roofline,
            "elapsed_s": elapsed, "ms_per_step": elapsed / args.steps * 1e3,
            "queries_per_s": args.n_query / (elapsed / args.steps),
+           "blocking_half_batches_in_flight": blocking_parts,
+           "blocking_as_one_batch": {"ms_per_step": elapsed_unsplit * 1e3,
+                                     "queries_per_s": args.n_query / elapsed_unsplit,
+                                     "results": "bit-identical to the split steps"},
            "recall_at_10": recall_at_k(ids, gt),
            "graph_build_s_per_gpu": build_kernel_s, "graph_build_wall_s": build_wall_s,
            "query_kernel_ms_sum_over_local_shards": float(np.mean(kernel_ms))}
@@ -963,6 +981,7 @@ def run_in_process(args, ggnn):
     el, (ids, dists) = timed(step, args.steps, torch.cuda.synchronize)
     out = {"form": "one handle, set_gpus(%s), shard size %d" % (gpus, args.n_base),
            "exchange": eng.last_exchange(), "queries_per_s": args.n_query / el,
+           "blocking_half_batches_in_flight": eng.last_query_parts(),
            "ms_per_step": el * 1e3, "graph_build_wall_s": build_wall_s,
            "query_kernel_ms_max_over_gpus": eng.last_timing_ms()["query_ms"],
            "results": "merged [Nq, K] on the host (as the reference returns them)"}
@@ -1041,17 +1060,21 @@ def run_sharded(args, device, ggnn, world, rank):
         return bool(ok.item())
 
     ref_steps = max(5, args.steps // 2)
-    main_base = args.n_base
+    main_base, main_dim = args.n_base, args.dim
     cases = []
     skipped = []
-    for n_base in [main_base] + ([args.secondary_n_base] if args.secondary_n_base and
-                                 args.secondary_n_base != main_base else []):
-        if n_base != main_base and not still_time(args.optional_budget_s + 90):
-            skipped.append(f"secondary base of 8 x {n_base}: run already longer than "
+    # secondary series: 8 shards of the N=1 configuration's shape (SIFT1M-shaped rows of 128)
+    series = [(main_base, main_dim)]
+    if args.secondary_n_base and (args.secondary_n_base, 128) != (main_base, main_dim):
+        series.append((args.secondary_n_base, 128))
+    for n_base, dim in series:
+        if (n_base, dim) != (main_base, main_dim) and not still_time(args.optional_budget_s + 90):
+            skipped.append(f"secondary base of 8 x {n_base} x {dim}: run already longer than "
                            f"{args.optional_budget_s + 90:.0f} s")
             break
-        args.n_base = n_base
+        args.n_base, args.dim = n_base, dim
         case = sharded_case(args, device, world, rank, spg, cpu_group)
+        case["dim"] = dim
         # the one-GPU point of the series on the SAME base, measured by rank 0 while the others wait
         one = None
         if rank == 0 and not args.no_scaling_reference:
@@ -1062,7 +1085,7 @@ def run_sharded(args, device, ggnn, world, rank):
         barrier()
         # ... and the one-handle form (in-engine RCCL) in a child process of rank 0
         inproc = None
-        if not args.no_in_process and n_base == main_base:
+        if not args.no_in_process and (n_base, dim) == (main_base, main_dim):
             if still_time(args.optional_budget_s):
                 if rank == 0:
                     inproc = in_process_child(args, n_base, args.in_process_timeout)
@@ -1077,14 +1100,14 @@ def run_sharded(args, device, ggnn, world, rank):
             if "queries_per_s" in inproc:
                 inproc["speedup_vs_one_gpu_same_base"] = speedups(inproc, one)
         cases.append(case)
-    args.n_base = main_base
+    args.n_base, args.dim = main_base, main_dim
 
     if rank == 0:
         main, nq = cases[0], args.n_query
         total = TOTAL_SHARDS * main_base
         sp = main["speedup_vs_one_gpu_same_base"] or {}
         out = {
-            "metric": "queries/sec @ recall@10 (SIFT1M-shaped shards, k=10)",
+            "metric": "queries/sec @ recall@10 (100M-point base sharded over the GPUs, k=10)",
             "value": main["queries_per_s"], "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -1111,7 +1134,7 @@ def run_sharded(args, device, ggnn, world, rank):
             "in_process_handle": main.get("in_process_handle"),
             "secondary_base": (None if len(cases) < 2 else dict(
                 cases[1], note=f"the same series on {TOTAL_SHARDS} x {cases[1]['n_base_per_shard']} "
-                               "points (the round-1/2 default)")),
+                               f"x {cases[1]['dim']} (8 shards of the N=1 configuration's shape)")),
             "roofline": main.get("roofline"), "cpu_baseline": None,
             "note": "N=1 of this command is the BASELINE single-shard configuration (1M points); "
                     "the multi-GPU series keeps the BASE fixed (north star: 100M points) instead, "
@@ -1148,7 +1171,9 @@ def main():
                     help="N>1: the one-handle child is skipped when the run is already longer than "
                          "this, the secondary base 90 s later (the line matters more)")
     ap.add_argument("--n-query", type=int, default=10_000)
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dim", type=int, default=None,
+                    help="default: 128 at N=1 (BASELINE configs[1], SIFT1M shape); 96 at N>1 "
+                         "(BASELINE configs[3], the DEEP100M shape: 100M x 96 over the GPUs)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--k-build", type=int, default=24)
     ap.add_argument("--tau-build", type=float, default=0.5)
@@ -1185,6 +1210,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.n_base is None:
         args.n_base = 12_500_000 if (world > 1 or args.in_process) else 1_000_000
+    if args.dim is None:
+        args.dim = 96 if (world > 1 or args.in_process) else 128
     if args.in_process:
         import ggnn_amd as ggnn
         ggnn.set_log_level(-1)

@@ -61,6 +61,9 @@ class ShardedGGNN:
             engine.set_return_results_on_gpu(True)
         self.engine = engine
         self.n_local = None
+        # blocking query() as two half-batches in flight: None = from 4096 queries, True / False
+        self.split_blocking = None
+        self.last_query_parts = 1
 
     def set_base(self, base, is_local_slice=False):
         t = _as_tensor(base, what="base")
@@ -99,8 +102,26 @@ class ShardedGGNN:
 
     def query(self, query, k_query, tau_query, max_iterations=400,
               measure=DistanceMeasure.Euclidean):
-        """every rank returns the merged global [Nq, K] result (device tensors)"""
-        ids, dists = self.engine.query(query, k_query, tau_query, max_iterations, measure)
+        """every rank returns the merged global [Nq, K] result (device tensors).
+
+        A batch of 4096 queries or more (`split_blocking`) runs as two half-batches in flight:
+        the local search of the second half is enqueued before the first is exchanged and merged,
+        so the all-gather over xGMI and the merge hide behind a traversal instead of following it
+        -- the pipelining of query_async / finish without the caller having to use it.  The
+        result is the concatenation, bit-identical to the unsplit call."""
+        t = _as_tensor(query, what="query")
+        nq = int(t.shape[0])
+        split = self.split_blocking if self.split_blocking is not None else nq >= 4096
+        if split and nq >= 2 and hasattr(self.engine, "query_async"):
+            h = nq // 2
+            first = self.query_async(t[:h], k_query, tau_query, max_iterations, measure, slot=0)
+            second = self.query_async(t[h:], k_query, tau_query, max_iterations, measure, slot=1)
+            a = self.finish(first)
+            b = self.finish(second)
+            self.last_query_parts = 2
+            return torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+        self.last_query_parts = 1
+        ids, dists = self.engine.query(t, k_query, tau_query, max_iterations, measure)
         return self._exchange(ids, dists, int(k_query))
 
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):

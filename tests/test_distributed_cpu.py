@@ -45,6 +45,14 @@ class OracleEngine:
         ids, d = self.orc.bf_query(self.base, query.numpy(), k, int(measure), threads=2)
         return torch.from_numpy(ids), torch.from_numpy(d)
 
+    # the asynchronous surface (nothing is asynchronous on the CPU: the ticket holds the result)
+    def query_async(self, query, k, tau, iters=400, measure=0, slot=0):
+        self.slots_used = getattr(self, "slots_used", []) + [slot]
+        return self.query(query, k, tau, iters, measure)
+
+    def synchronize(self, slot=None):
+        pass
+
 
 def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -83,6 +91,16 @@ def _worker(rank, world, port, tmp):
         uniq[:, :-1] &= r_d[:, :-1] != r_d[:, 1:]
         assert np.array_equal(ids.numpy()[uniq], r_ids[uniq])
         assert ids.numpy().min() >= 0 and ids.numpy().max() < N
+        # a blocking batch split into two half-batches in flight (default from 4096 queries): the
+        # same collective sequence on every rank, the concatenated result identical
+        assert sg.last_query_parts == 1
+        sg.split_blocking = True
+        ids2, d2 = sg.query(query, K, 0.6, 200)
+        assert sg.last_query_parts == 2 and sg.engine.slots_used[-2:] == [0, 1]
+        assert torch.equal(ids2, ids) and torch.equal(d2, d)
+        ids3, d3 = sg.query(query[:7], K, 0.6, 200)       # odd count: halves of 3 and 4
+        assert torch.equal(ids3, ids[:7]) and torch.equal(d3, d[:7])
+        sg.split_blocking = None
         with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:

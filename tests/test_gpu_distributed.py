@@ -81,6 +81,8 @@ def test_bench_two_ranks_strong_scaling_line(tmp_path):
     assert d["unit"] == "queries/s" and d["scaling"] == "strong" and d["higher_is_better"] is True
     assert abs(d["value"] - 600 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "8 shards x 20000" in d["config"]["workload"]
+    assert "x 96 f32" in d["config"]["workload"]          # BASELINE configs[3]: the DEEP100M shape
+    assert d["secondary_base"] is None or d["secondary_base"]["dim"] == 128
     assert d["recall_at_10"] > 0.95
     pip = d["pipelined_batches"]
     assert pip.get("results_equal_blocking") is True and pip["queries_per_s"] > 0, pip
@@ -150,6 +152,10 @@ t = s.query_async(q, 10, 0.9, 200, slot=1)
 ids2, d2 = s.finish(t)
 assert ids.is_cuda and tuple(ids.shape) == (500, 10)
 assert torch.equal(ids, ids2) and torch.equal(d, d2)
+assert s.last_query_parts == 1
+s.split_blocking = True           # two half-batches in flight (default from 4096 queries)
+ids3, d3 = s.query(q, 10, 0.9, 200)
+assert s.last_query_parts == 2 and torch.equal(ids, ids3) and torch.equal(d, d3)
 ref = ggnn.GGNN(); ref.set_base_reference(base); ref.set_shard_size(20000)
 ref.set_return_results_on_gpu(True); ref.build(24, 0.5, 1)
 rg, rd = ref.bf_query(q, 10)
