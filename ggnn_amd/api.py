@@ -161,6 +161,7 @@ class Graph:
 # GGNN (nanobind.cu:184-268 over ggnn.cuh:42-182)
 # ---------------------------------------------------------------------------------------------
 _ASYNC_SLOTS = 4   # DeviceCtx::kShardStreams: slots that map to the same engine stream
+_MAX_TICKETS_PER_SLOT = 64   # query_async batches whose tensors are held per slot before it is drained
 
 
 class QueryTicket:
@@ -310,7 +311,9 @@ class GGNN:
         knows nothing about.  The engine object therefore keeps the query tensor and both
         result tensors referenced until `synchronize()` (of that slot) has returned, whatever
         the caller does with its own references -- a temporary passed as `query`, or a
-        rebound loop variable, cannot be recycled under a running kernel."""
+        rebound loop variable, cannot be recycled under a running kernel.  At most
+        `_MAX_TICKETS_PER_SLOT` batches are held per slot: enqueueing one more first synchronises
+        that slot and releases them."""
         t = _as_tensor(query, what="query")
         if self._num_gpus > 1 or _lib.get_hook("EXCHANGE") == 1:
             # several GPUs (or the forced RCCL path of the tests): merged [Nq, k] results; host-side tensors are page-locked so that the
@@ -334,7 +337,14 @@ class GGNN:
                                            int(max_iterations), int(measure), ids.data_ptr(),
                                            dists.data_ptr(), int(slot)))
         ticket = QueryTicket(t, ids, dists, int(slot))
-        self._inflight.setdefault(int(slot) % _ASYNC_SLOTS, []).append(ticket)
+        held = self._inflight.setdefault(int(slot) % _ASYNC_SLOTS, [])
+        if len(held) >= _MAX_TICKETS_PER_SLOT:
+            # a serving loop that waits some other way (its own events, torch.cuda.synchronize)
+            # never calls synchronize(): the references held for the kernels' sake must not grow
+            # without bound -- the slot is drained (its batches ran long ago) and released
+            self.synchronize(slot)
+            held = self._inflight.setdefault(int(slot) % _ASYNC_SLOTS, [])
+        held.append(ticket)
         return ticket
 
     def synchronize(self, slot=None):

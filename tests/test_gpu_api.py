@@ -675,3 +675,23 @@ def test_rccl_failure_falls_back_to_peer_copies():
         eng.synchronize()
     for ids, d in (a, b, c, (t0.ids.cpu(), t0.dists.cpu()), (t1.ids.cpu(), t1.dists.cpu())):
         assert torch.equal(ids, ref[0]) and torch.equal(d, ref[1])
+
+
+def test_query_async_tickets_are_bounded_without_synchronize():
+    """A serving loop that never calls synchronize() (it waits some other way): the tensors the
+    engine holds for its kernels' sake stay bounded -- a slot is drained and released once it
+    holds _MAX_TICKETS_PER_SLOT batches."""
+    import ggnn_amd as ggnn
+    from ggnn_amd import api
+    base, q = make_int_data(4000, 64, 687), make_int_data(64, 64, 688)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_return_results_on_gpu(True)
+    eng.build(24, 0.5, 1)
+    qd = torch.from_numpy(q).cuda()
+    ref = eng.query(qd, 10, 0.7, 100)
+    tickets = [eng.query_async(qd, 10, 0.7, 100, slot=1) for _ in range(api._MAX_TICKETS_PER_SLOT + 5)]
+    assert len(eng._inflight[1]) == 5
+    assert all(t.done for t in tickets[:api._MAX_TICKETS_PER_SLOT])
+    eng.synchronize()
+    assert all(torch.equal(t.ids, ref[0]) and torch.equal(t.dists, ref[1]) for t in tickets)
