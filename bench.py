@@ -439,8 +439,8 @@ def build_roofline(args, ggnn, base):
                    "delivers because consecutive points share neighbourhoods (rows served by the "
                    "L2s and the Infinity Cache): `traffic` is what reached the fabric"}
     for kname, w, row_bytes_per_pop, needle in (
-            ("merge_kernel", work["merge"], k * 4, "merge_kernel"),
-            ("sym_kernel", work["sym"], (k + k // 2) * 4, "sym_kernel")):
+            ("merge_kernel", work["merge"], k * 4, "::merge_kernel<"),
+            ("sym_kernel", work["sym"], (k + k // 2) * 4, "::sym_kernel<")):
         if not w["launches"]:
             continue
         own = (w["float_rows"] * d * esz + w["code_rows"] * code_dim + w["pops"] * row_bytes_per_pop

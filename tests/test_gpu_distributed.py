@@ -106,7 +106,7 @@ def test_bench_single_gpu_line_small():
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert d["recall_at_10"] > 0.95 and d["recall_at_10_heldout_queries"] > 0.95
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and 0 < rf["frac"] and "secondary" in rf
+    assert rf["bound"] in ("hbm", "valu") and 0 < rf["frac"] and "secondary" in rf
     assert rf["without_prescreen"]["results"].startswith("bit-identical")
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
