@@ -163,6 +163,14 @@ struct Shard {
     return (static_cast<size_t>(c.N_all) * c.KBuild + 2 * static_cast<size_t>(c.ST_all)) * 4 +
            2 * sizeof(float);
   }
+  // out-of-core shards: the pool is a slot buffer of the GPU's SwapState
+  void view(const ggnn_graph_config& c, void* slot_pool)
+  {
+    graph = static_cast<int32_t*>(slot_pool);
+    translation = graph + static_cast<size_t>(c.N_all) * c.KBuild;
+    selection = translation + c.ST_all;
+    nn1_stats = reinterpret_cast<float*>(selection + c.ST_all);
+  }
   void allocate(const ggnn_graph_config& c)
   {
     pool.alloc(align8(pool_bytes(c)));
@@ -240,6 +248,45 @@ struct RcclError : Error {
                                                          Rccl::get().GetErrorString(_r));  \
   } while (0)
 
+// Out-of-core shards of one GPU (reference: GPUInstance's d_buffers / h_buffers /
+// part files, gpu_instance.cu:135-227, 371-497).  Only when the shards of a GPU do not fit next
+// to each other -- at every BASELINE configuration they do, and then none of this exists:
+//   * `slots` GPU buffers (graph pool + base shard); local shard s lives in slot s % slots;
+//   * `host.size()` page-locked host buffers for the graph pools (shard s in buffer s % host
+//     buffers; ggnn_set_cpu_memory_limit bounds them), the rest as part_<shard>.ggnn files in
+//     the working directory -- the reference's three tiers;
+//   * one copy stream: the shard a query needs next is uploaded while the current one is
+//     searched (the reference uses one io thread per buffer for the same purpose).
+struct SwapState {
+  int device{0};
+  uint32_t slots{0};
+  std::vector<DeviceBuffer> pool, base;     // [slots]
+  std::vector<int> pool_shard, base_shard;  // local shard held, -1: none
+  std::vector<PinnedBuffer> host;           // [host buffers]
+  std::vector<int> host_shard;
+  std::vector<uint8_t> on_disk;             // [shards per GPU]: part file is current
+  hipStream_t io{nullptr};
+  std::vector<hipEvent_t> uploaded, consumed;  // [slots]: copies done (io) / last kernel done (ctx)
+  bool base_borrowed{false};                // the base slice is device memory of this GPU already
+  SwapState() = default;
+  SwapState(const SwapState&) = delete;
+  SwapState& operator=(const SwapState&) = delete;
+  ~SwapState()
+  {
+    if (io || !uploaded.empty()) {
+      (void)hipSetDevice(device);
+      for (hipEvent_t e : uploaded)
+        if (e)
+          (void)hipEventDestroy(e);
+      for (hipEvent_t e : consumed)
+        if (e)
+          (void)hipEventDestroy(e);
+      if (io)
+        (void)hipStreamDestroy(io);
+    }
+  }
+};
+
 // everything one GPU owns (GPUInstance of the reference, gpu_instance.cuh:60-221, reduced to
 // resident shards)
 struct DeviceCtx {
@@ -260,6 +307,7 @@ struct DeviceCtx {
   hipEvent_t shard_done[kShardStreams] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_ready{nullptr};
   DeviceBuffer bf_rescanned;    // one uint32: queries of the last bf_query answered by the scan
+  std::unique_ptr<SwapState> swap;  // out-of-core shards (null: every shard resident)
   // Result staging of query() / query_async(): grown on demand, kept between calls.  One set per
   // lane: lanes [0, kShardStreams) belong to the asynchronous slots (their streams), lane
   // kBlockingLane to the blocking query(): its staging, exchange and result copies run on `stream`,
@@ -325,6 +373,7 @@ struct DeviceCtx {
     d_base = o.d_base;
     first_shard = o.first_shard;
     shards = std::move(o.shards);
+    swap = std::move(o.swap);
     return *this;
   }
   ~DeviceCtx()
@@ -561,8 +610,189 @@ struct ggnn_handle {
 
   const void* shard_base(const DeviceCtx& ctx, uint32_t local_shard) const
   {
+    if (ctx.swap && !ctx.swap->base_borrowed)  // (valid after acquire_shard of this shard)
+      return ctx.swap->base[local_shard % ctx.swap->slots].p;
     return static_cast<const uint8_t*>(ctx.d_base) +
            static_cast<size_t>(local_shard) * cfg.N * row_bytes();
+  }
+
+  // ---- out-of-core shards (SwapState) -----------------------------------------------------------
+  bool swapping() const { return !devs.empty() && devs[0].swap != nullptr; }
+
+  // GPU slots per device: 0 = every shard resident (the normal case).  Hook RESIDENT_SHARDS forces
+  // a number (tests); otherwise the shards are counted against the free device memory minus
+  // ggnn_set_reserved_gpu_memory, as GPUInstance::allocateGraph does (gpu_instance.cu:157-186).
+  uint32_t plan_gpu_slots(const DeviceCtx& ctx, uint32_t spg, bool base_on_this_gpu) const
+  {
+    const int64_t forced = hook(kHookResidentShards);
+    if (forced > 0)
+      return forced >= spg ? 0u : static_cast<uint32_t>(forced);
+    size_t free_b = 0, total_b = 0;
+    GGNN_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    GGNN_REQUIRE(free_b > reserved_gpu_memory, GGNN_OUT_OF_MEMORY,
+                 "GPU memory does not suffice for the reserved amount.");
+    free_b -= reserved_gpu_memory;
+    const size_t pool_b = align8(Shard::pool_bytes(cfg));
+    const size_t base_b = base_on_this_gpu ? 0 : static_cast<size_t>(cfg.N) * row_bytes();
+    // construction scratch of one shard (build_device) + the optional 8-bit copy of resident shards
+    const size_t scratch_b = static_cast<size_t>(cfg.N) * (cfg.KBuild * 4 + cfg.KF * 4 + 16);
+    const size_t codes_b = (prescreen && base_dtype == GGNN_F32 && pad_D >= 64)
+                               ? static_cast<size_t>(cfg.N) * prescreen_code_dim(pad_D) : 0;
+    const size_t resident_need = spg * (pool_b + base_b + codes_b) + scratch_b;
+    (void)ctx;
+    if (resident_need <= free_b)
+      return 0;
+    GGNN_REQUIRE(free_b > scratch_b + pool_b + base_b, GGNN_OUT_OF_MEMORY,
+                 "GPU memory does not suffice for a single shard. use smaller shards.");
+    return static_cast<uint32_t>(std::min<size_t>(spg - 1, (free_b - scratch_b) / (pool_b + base_b)));
+  }
+
+  void setup_swap(DeviceCtx& ctx, uint32_t slots, bool base_on_this_gpu)
+  {
+    auto sw = std::make_unique<SwapState>();
+    sw->device = ctx.device;
+    sw->slots = slots;
+    sw->base_borrowed = base_on_this_gpu;
+    const size_t pool_b = align8(Shard::pool_bytes(cfg));
+    // host buffers first (fail early, as the reference does): ggnn_set_cpu_memory_limit bounds them
+    const size_t host_n = std::max<size_t>(
+        1, std::min<size_t>(shards_per_gpu, cpu_memory_limit / std::max<size_t>(1, pool_b)));
+    GGNN_REQUIRE(cpu_memory_limit >= pool_b, GGNN_OUT_OF_MEMORY,
+                 "CPU memory does not suffice for a single shard. use smaller shards.");
+    sw->host.resize(host_n);
+    for (PinnedBuffer& b : sw->host)
+      b.grow(pool_b);
+    sw->host_shard.assign(host_n, -1);
+    sw->on_disk.assign(shards_per_gpu, 0);
+    sw->pool.resize(slots);
+    sw->base.resize(slots);
+    for (uint32_t k = 0; k < slots; ++k) {
+      sw->pool[k].alloc(pool_b);
+      if (!base_on_this_gpu)
+        sw->base[k].alloc(static_cast<size_t>(cfg.N) * row_bytes());
+    }
+    sw->pool_shard.assign(slots, -1);
+    sw->base_shard.assign(slots, -1);
+    GGNN_HIP_CHECK(hipStreamCreateWithFlags(&sw->io, hipStreamNonBlocking));
+    sw->uploaded.assign(slots, nullptr);
+    sw->consumed.assign(slots, nullptr);
+    for (uint32_t k = 0; k < slots; ++k) {
+      GGNN_HIP_CHECK(hipEventCreateWithFlags(&sw->uploaded[k], hipEventDisableTiming));
+      GGNN_HIP_CHECK(hipEventCreateWithFlags(&sw->consumed[k], hipEventDisableTiming));
+    }
+    ctx.swap = std::move(sw);
+    GGNN_LOG(1, "[GPU: %d] out-of-core shards: %u GPU slot(s), %zu host buffer(s) for %u shards%s",
+             ctx.device, slots, host_n, shards_per_gpu,
+             host_n < shards_per_gpu ? ", the rest on disk" : "");
+  }
+
+  // rows of local shard si -> its slot's base buffer, on `st`
+  void upload_base_shard(DeviceCtx& ctx, uint32_t si, hipStream_t st)
+  {
+    SwapState& sw = *ctx.swap;
+    if (sw.base_borrowed)
+      return;
+    const uint32_t k = si % sw.slots;
+    if (sw.base_shard[k] == static_cast<int>(si))
+      return;
+    const size_t es = dtype_size(base_dtype);
+    const uint64_t row0 = (static_cast<uint64_t>(ctx.first_shard) + si) * cfg.N;
+    const uint8_t* src = static_cast<const uint8_t*>(base_src) + row0 * base_D * es;
+    const hipMemcpyKind kind = base_loc == GGNN_GPU ? hipMemcpyDefault : hipMemcpyHostToDevice;
+    if (pad_D != base_D) {
+      GGNN_HIP_CHECK(hipMemsetAsync(sw.base[k].p, 0, sw.base[k].bytes, st));
+      GGNN_HIP_CHECK(hipMemcpy2DAsync(sw.base[k].p, pad_D * es, src, base_D * es, base_D * es, cfg.N,
+                                      kind, st));
+    }
+    else
+      GGNN_HIP_CHECK(hipMemcpyAsync(sw.base[k].p, src, static_cast<size_t>(cfg.N) * pad_D * es, kind, st));
+    sw.base_shard[k] = static_cast<int>(si);
+  }
+
+  // graph pool of local shard si in its host buffer (read from its part file if it is not there)
+  void* host_pool_of(DeviceCtx& ctx, uint32_t si)
+  {
+    SwapState& sw = *ctx.swap;
+    const size_t h = si % sw.host.size();
+    if (sw.host_shard[h] != static_cast<int>(si)) {
+      GGNN_REQUIRE(sw.on_disk[si], GGNN_INVALID_STATE,
+                   "graph part " + std::to_string(ctx.first_shard + si) + " is neither in memory nor on disk");
+      // (the buffer may still feed an upload of the shard it held: uploads are synchronous w.r.t.
+      // the host here because every acquire waits for `uploaded` before it returns to the loop)
+      GGNN_HIP_CHECK(hipStreamSynchronize(sw.io));
+      read_part(ctx.first_shard + si, sw.host[h].p);
+      sw.host_shard[h] = static_cast<int>(si);
+    }
+    return sw.host[h].p;
+  }
+
+  // Makes local shard si usable on the GPU: graph pool and base rows in slot si % slots, the
+  // shard's pointers set.  Copies run on `st` (the io stream for a prefetch); the slot's previous
+  // user is waited for through its `consumed` event, the caller orders its kernels behind
+  // `uploaded`.
+  void acquire_shard(DeviceCtx& ctx, uint32_t si, hipStream_t st, bool with_graph = true)
+  {
+    SwapState& sw = *ctx.swap;
+    const uint32_t k = si % sw.slots;
+    Shard& sh = ctx.shards[si];
+    const bool need_pool = with_graph && sw.pool_shard[k] != static_cast<int>(si);
+    const bool need_base = !sw.base_borrowed && sw.base_shard[k] != static_cast<int>(si);
+    if (need_pool || need_base || !with_graph)
+      GGNN_HIP_CHECK(hipStreamWaitEvent(st, sw.consumed[k], 0));
+    if (need_pool) {
+      void* hp = host_pool_of(ctx, si);
+      GGNN_HIP_CHECK(hipMemcpyAsync(sw.pool[k].p, hp, Shard::pool_bytes(cfg), hipMemcpyHostToDevice, st));
+      sw.pool_shard[k] = static_cast<int>(si);
+    }
+    if (!with_graph)
+      sw.pool_shard[k] = static_cast<int>(si);  // about to be built in place
+    upload_base_shard(ctx, si, st);
+    sh.view(cfg, sw.pool[k].p);
+    GGNN_HIP_CHECK(hipEventRecord(sw.uploaded[k], st));
+  }
+  // the kernels enqueued on `st` so far are the last users of shard si's slot
+  void shard_consumed(DeviceCtx& ctx, uint32_t si, hipStream_t st)
+  {
+    SwapState& sw = *ctx.swap;
+    GGNN_HIP_CHECK(hipEventRecord(sw.consumed[si % sw.slots], st));
+  }
+  // after build: the graph pool of shard si goes to its host buffer and, when the host buffers do
+  // not hold every shard, to its part file at once (swapOutPart, gpu_instance.cu:372-425)
+  void retire_built_shard(DeviceCtx& ctx, uint32_t si)
+  {
+    SwapState& sw = *ctx.swap;
+    const uint32_t k = si % sw.slots;
+    const size_t h = si % sw.host.size();
+    GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    GGNN_HIP_CHECK(hipMemcpy(sw.host[h].p, sw.pool[k].p, Shard::pool_bytes(cfg), hipMemcpyDeviceToHost));
+    sw.host_shard[h] = static_cast<int>(si);
+    sw.on_disk[si] = 0;
+    if (sw.host.size() < shards_per_gpu) {
+      if (graph_dir.empty())
+        graph_dir = std::filesystem::current_path();
+      write_part(ctx.first_shard + si, sw.host[h].p);
+      sw.on_disk[si] = 1;
+    }
+  }
+  void write_part(uint32_t global_shard, const void* host)
+  {
+    const auto file = part_file(global_shard);
+    std::ofstream f(file, std::ios::binary | std::ios::trunc);
+    GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "cannot open " + file.string());
+    f.write(static_cast<const char*>(host), static_cast<std::streamsize>(Shard::pool_bytes(cfg)));
+    GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short write to " + file.string());
+  }
+  void read_part(uint32_t global_shard, void* host)
+  {
+    const auto file = part_file(global_shard);
+    std::error_code ec;
+    const auto sz = std::filesystem::file_size(file, ec);
+    // the reference validates by file size only (gpu_instance.cu:413-415)
+    GGNN_REQUIRE(!ec && sz == Shard::pool_bytes(cfg), GGNN_IO_ERROR,
+                 "missing or mismatching graph file " + file.string());
+    std::ifstream f(file, std::ios::binary);
+    f.read(static_cast<char*>(host), static_cast<std::streamsize>(Shard::pool_bytes(cfg)));
+    GGNN_REQUIRE(f.good(), GGNN_IO_ERROR, "short read from " + file.string());
   }
 
   // GGNNImpl::prepare, ggnn.cu:154-203
@@ -608,15 +838,27 @@ struct ggnn_handle {
         ctx.device = gpus[i];
         ctx.first_shard = i * shards_per_gpu;
         ctx.activate();
-        if (!reuse)
+        ctx.swap.reset();
+        // do the shards of this GPU fit next to each other?  (at every BASELINE configuration:
+        // yes -- 288 GB; otherwise they take turns in a few GPU slots, SwapState)
+        const uint8_t* slice = static_cast<const uint8_t*>(base_src) +
+                               static_cast<uint64_t>(ctx.first_shard) * n * base_D * dtype_size(base_dtype);
+        const bool base_here = reuse || (pad_D == base_D && base_loc == GGNN_GPU &&
+                                         base_gpu == ctx.device &&
+                                         (reinterpret_cast<uintptr_t>(slice) & 15u) == 0);
+        const uint32_t slots = shards_per_gpu > 1 ? plan_gpu_slots(ctx, shards_per_gpu, base_here) : 0;
+        if (!reuse && (!slots || base_here))
           stage_base_slice(ctx, static_cast<uint64_t>(ctx.first_shard) * n,
                            static_cast<uint64_t>(shards_per_gpu) * n);
         ctx.shards.clear();
         ctx.shards.resize(shards_per_gpu);
         for (uint32_t s = 0; s < shards_per_gpu; ++s) {
           ctx.shards[s].global_id = ctx.first_shard + s;
-          ctx.shards[s].allocate(cfg);
+          if (!slots)
+            ctx.shards[s].allocate(cfg);
         }
+        if (slots)
+          setup_swap(ctx, slots, base_here);
       }
     }
     catch (...) {
@@ -678,6 +920,8 @@ struct ggnn_handle {
     };
 
     for (uint32_t si = 0; si < ctx.shards.size(); ++si) {
+      if (ctx.swap)  // out-of-core shards: this shard's rows into its slot, the pool is built in place
+        acquire_shard(ctx, si, stream, /*with_graph=*/false);
       // the pre-screen copy serves the merge kernel too (made outside the timed region: it
       // depends on the base only and is kept for the queries)
       const bool use_ps = ensure_prescreen(ctx, si, measure);
@@ -819,6 +1063,10 @@ struct ggnn_handle {
       }
       const float ms = timer.stop();
       ctx.build_ms += ms;
+      if (ctx.swap) {
+        retire_built_shard(ctx, si);
+        shard_consumed(ctx, si, stream);
+      }
       sh.ready = true;
       GGNN_LOG(0, "[GPU: %d] build(): part %u => %.3f s [%u points -> %.3f us/point]", ctx.device,
                sh.global_id, ms / 1000.f, N, ms * 1000.f / static_cast<float>(N));
@@ -849,6 +1097,10 @@ struct ggnn_handle {
   // holds its slice
   void release_caller_copy()
   {
+    // out-of-core shards re-read their rows from the caller's / the engine's copy at every swap
+    for (const DeviceCtx& ctx : devs)
+      if (ctx.swap && !ctx.swap->base_borrowed)
+        return;
     bool borrowed_from_copy = false;
     for (const DeviceCtx& ctx : devs)
       borrowed_from_copy |= (ctx.base_copy.p == nullptr);
@@ -902,7 +1154,9 @@ struct ggnn_handle {
   bool ensure_prescreen(DeviceCtx& ctx, uint32_t si, ggnn_measure measure)
   {
     Shard& sh = ctx.shards[si];
-    if (!prescreen || base_dtype != GGNN_F32 || pad_D < 64)
+    // (out-of-core shards: a per-shard copy that would have to be re-coded at every swap; the
+    // kernels read the float rows, results are the same)
+    if (!prescreen || base_dtype != GGNN_F32 || pad_D < 64 || ctx.swap)
       return false;
     if (sh.ps_state != 0 && sh.ps_measure != measure) {
       // the codes belong to the other measure: code again.  Batches still in flight on this GPU
@@ -976,7 +1230,7 @@ struct ggnn_handle {
     // Several resident shards: one launch per shard, spread over a few streams and NOT separated
     // by host synchronisation, so the under-occupied tail of a 10k-wave launch is filled by the
     // next shard's waves (hook SHARD_OVERLAP = 0: one launch at a time, as for the work counters).
-    const bool overlap = spg > 1 && !collect_counters && hook(kHookShardOverlap) != 0;
+    const bool overlap = spg > 1 && !collect_counters && hook(kHookShardOverlap) != 0 && !ctx.swap;
     if (overlap) {
       for (uint32_t si = 0; si < spg; ++si)
         (void)ensure_prescreen(ctx, si, measure);  // may code a shard (synchronises): do it first
@@ -987,6 +1241,16 @@ struct ggnn_handle {
       GGNN_HIP_CHECK(hipEventRecord(ctx.ev_a, stream));
     }
     for (uint32_t si = 0; si < spg; ++si) {
+      if (ctx.swap) {
+        // out-of-core shards (swapInPart / waitForPart, gpu_instance.cu:661-688): this shard is
+        // in its slot (uploaded as the previous one's prefetch, or right now), the next one
+        // starts travelling on the copy stream while this one is searched
+        SwapState& sw = *ctx.swap;
+        acquire_shard(ctx, si, sw.io);
+        GGNN_HIP_CHECK(hipStreamWaitEvent(stream, sw.uploaded[si % sw.slots], 0));
+        if (si + 1 < spg && sw.slots > 1)
+          acquire_shard(ctx, si + 1, sw.io);
+      }
       const bool use_ps = ensure_prescreen(ctx, si, measure);
       const Shard& sh = ctx.shards[si];
       QueryLaunch ql{shard_base(ctx, si),
@@ -1022,6 +1286,8 @@ struct ggnn_handle {
       }
       EventTimer timer(stream, ctx.ev_a, ctx.ev_b);
       launch_query(ql, stream);
+      if (ctx.swap)
+        shard_consumed(ctx, si, stream);
       const float ms = timer.stop();
       ctx.query_ms += ms;
       GGNN_LOG(0, "[GPU: %d] query part %u => ms: %.3f [%u points query -> %.3f us/point]",
@@ -1088,7 +1354,7 @@ struct ggnn_handle {
       const int64_t split = hook(kHookQuerySplit);
       const bool several = devs.size() > 1 || hook(kHookExchange) == 1;
       const bool want = split >= 0 ? split == 1 : nq >= 4096;
-      if (several && !direct && !collect_counters && want && nq >= 2) {
+      if (several && !direct && !collect_counters && want && nq >= 2 && !swapping()) {
         query_split(q, nq, D, dtype, loc, q_gpu, k_query, tau_query, max_iterations, measure,
                     ids_out, dists_out);
         return;
@@ -1426,6 +1692,9 @@ struct ggnn_handle {
     check_query(Nq, D, dtype, d_query);
     GGNN_REQUIRE(!Nq || (d_ids != nullptr && d_dists != nullptr), GGNN_INVALID_ARGUMENT,
                  "result pointers are null");
+    GGNN_REQUIRE(!swapping(), GGNN_UNSUPPORTED,
+                 "asynchronous queries need every shard resident on its GPU (the shards of this "
+                 "handle take turns in GPU memory)");
     if (!Nq)
       return;
     const uint32_t nq = static_cast<uint32_t>(Nq);
@@ -1550,6 +1819,23 @@ struct ggnn_handle {
     bf_ms = 0.f;
     if (!Nq)
       return;
+    // out-of-core shards with the rows on the host: the exhaustive scan needs the whole base on
+    // the GPU for the duration of the call (fails with GGNN_OUT_OF_MEMORY if that is too much)
+    DeviceBuffer whole_base;
+    const void* bf_base = ctx.d_base;
+    if (ctx.swap && !ctx.swap->base_borrowed) {
+      const size_t es = dtype_size(base_dtype);
+      whole_base.alloc(base_N * pad_D * es);
+      const hipMemcpyKind kind = base_loc == GGNN_GPU ? hipMemcpyDefault : hipMemcpyHostToDevice;
+      if (pad_D != base_D) {
+        GGNN_HIP_CHECK(hipMemsetAsync(whole_base.p, 0, whole_base.bytes, ctx.stream));
+        GGNN_HIP_CHECK(hipMemcpy2DAsync(whole_base.p, pad_D * es, base_src, base_D * es, base_D * es,
+                                        base_N, kind, ctx.stream));
+      }
+      else
+        GGNN_HIP_CHECK(hipMemcpyAsync(whole_base.p, base_src, whole_base.bytes, kind, ctx.stream));
+      bf_base = whole_base.p;
+    }
     Staged sq = stage_query(ctx, q, Nq, D, dtype, loc, q_gpu);
     const uint32_t nq = static_cast<uint32_t>(Nq);
     const bool direct = (out_loc == GGNN_GPU);
@@ -1564,7 +1850,7 @@ struct ggnn_handle {
     }
     if (!ctx.bf_rescanned.p)
       ctx.bf_rescanned.alloc(sizeof(uint32_t));
-    BfLaunch bl{ctx.d_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
+    BfLaunch bl{bf_base, sq.ptr, base_dtype, static_cast<uint32_t>(base_N), pad_D, nq, k_gt,
                 measure,    d_ids,  d_dists,    ctx.bf_rescanned.as<uint32_t>()};
     EventTimer timer(ctx.stream, ctx.ev_a, ctx.ev_b);
     launch_bf_query(bl, ctx.stream);
@@ -1594,6 +1880,15 @@ struct ggnn_handle {
     if (graph_dir.empty())
       graph_dir = std::filesystem::current_path();
     for_each_device([&](DeviceCtx& ctx) {
+      if (ctx.swap) {
+        // out-of-core shards: every pool is in its host buffer or already in its part file
+        for (uint32_t si = 0; si < ctx.shards.size(); ++si)
+          if (!ctx.swap->on_disk[si]) {
+            write_part(ctx.first_shard + si, host_pool_of(ctx, si));
+            ctx.swap->on_disk[si] = 1;
+          }
+        return;
+      }
       std::vector<char> host(Shard::pool_bytes(cfg));
       for (const Shard& sh : ctx.shards) {
         GGNN_HIP_CHECK(hipMemcpy(host.data(), sh.pool.p, host.size(), hipMemcpyDeviceToHost));
@@ -1625,6 +1920,19 @@ struct ggnn_handle {
   void load_shards()
   {
     for_each_device([&](DeviceCtx& ctx) {
+      if (ctx.swap) {
+        // out-of-core shards: the files are validated now and read when a shard is first needed
+        for (uint32_t si = 0; si < ctx.shards.size(); ++si) {
+          const auto file = part_file(ctx.first_shard + si);
+          std::error_code ec;
+          const auto sz = std::filesystem::file_size(file, ec);
+          GGNN_REQUIRE(!ec && sz == Shard::pool_bytes(cfg), GGNN_IO_ERROR,
+                       "missing or mismatching graph file " + file.string());
+          ctx.swap->on_disk[si] = 1;
+          ctx.shards[si].ready = true;
+        }
+        return;
+      }
       std::vector<char> host(Shard::pool_bytes(cfg));
       for (Shard& sh : ctx.shards) {
         const auto file = part_file(sh.global_id);
@@ -1996,7 +2304,13 @@ ggnn_status ggnn_get_graph(ggnn_t* h, uint32_t global_shard_id, ggnn_graph_view*
     GGNN_REQUIRE(h->has_graph(), GGNN_INVALID_STATE, "No graph has been built or loaded yet.");
     GGNN_REQUIRE(global_shard_id < h->num_shards(), GGNN_INVALID_STATE,
                  "Shard " + std::to_string(global_shard_id) + " does not exist.");
-    const DeviceCtx& ctx = h->devs[global_shard_id / h->shards_per_gpu];
+    DeviceCtx& ctx = h->devs[global_shard_id / h->shards_per_gpu];
+    if (ctx.swap) {
+      // out-of-core shards: the view is valid until another shard takes the slot
+      ctx.activate();
+      h->acquire_shard(ctx, global_shard_id % h->shards_per_gpu, ctx.stream);
+      GGNN_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    }
     const Shard& sh = ctx.shards[global_shard_id % h->shards_per_gpu];
     out->config = h->cfg;
     out->config.D = h->base_D;  // caller-visible dimension (rows are padded internally)

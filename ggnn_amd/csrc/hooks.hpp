@@ -17,6 +17,7 @@ enum Hook {
   kHookVisSlots,        // VIS_SLOTS        usable keys per bucket of the hashed visited set (1..8)
   kHookVisTagSet,       // VIS_TAG_SET      0 = rings of 481..2016 keys scanned instead of the tag set
   kHookQuerySplit,      // QUERY_SPLIT      -1 auto | 0 | 1: blocking multi-GPU query as two half-batches
+  kHookResidentShards,  // RESIDENT_SHARDS  0 auto (by free memory) | GPU slots per device for its shards
   kHookXcdMap,          // XCD_MAP          bit 0: merge, bit 1: sym -- XCD-contiguous point ranges
   kHookBfPoolKeepMb,    // BF_POOL_KEEP_MB  release threshold of the bf scratch pool
   kHookBfNoI8,          // BF_NO_I8         1 = uint8 bf_query through the float kernels

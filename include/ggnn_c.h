@@ -230,6 +230,9 @@ void ggnn_set_log_level(int level);
  *                             are scanned instead of probed through the 16-bit tag set
  *   QUERY_SPLIT        -1     blocking ggnn_query on several GPUs as two half-batches in flight:
  *                             -1 auto (from 4096 queries) | 0 never | 1 always (from 2 queries)
+ *   RESIDENT_SHARDS     0     GPU slots per device for its shards: 0 = decided from the free device
+ *                             memory (all resident whenever they fit); n < shards per GPU forces the
+ *                             out-of-core mode (shards take turns: GPU <-> pinned host <-> part files)
  *   XCD_MAP             3     bit 0: merge kernel, bit 1: sym kernel -- workgroups of one XCD take a
  *                             contiguous range of points (consecutive points share neighbourhoods)
  *   BF_POOL_KEEP_MB  1024     bytes the private bf_query scratch pool keeps between calls

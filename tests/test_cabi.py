@@ -238,7 +238,7 @@ def test_hooks_api(lib, monkeypatch):
     GGNN_TEST_HOOKS=1 (conftest sets it for the test session)."""
     from ggnn_amd import _lib
     header = open(os.path.join(ROOT, "include", "ggnn_c.h")).read()
-    names = ["PRESCREEN", "EXCHANGE", "SYM_PRESCREEN", "SHARD_OVERLAP", "VIS_SLOTS", "VIS_TAG_SET", "QUERY_SPLIT", "XCD_MAP",
+    names = ["PRESCREEN", "EXCHANGE", "SYM_PRESCREEN", "SHARD_OVERLAP", "VIS_SLOTS", "VIS_TAG_SET", "QUERY_SPLIT", "RESIDENT_SHARDS", "XCD_MAP",
              "BF_POOL_KEEP_MB", "BF_NO_I8", "BF_I8_V1", "BF_SLICES", "BF_NO_CENTER", "BF_TILES",
              "BF_I8_NOSHARE", "BF_I8_WARM", "BF_SCAN", "RCCL_FAIL_AFTER"]
     for n in names:
