@@ -330,8 +330,17 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   const uint32_t vis = args.cache - args.sorted;
   if (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0) {
     args.tag_bits = tag_set_bucket_bits(vis);
-    args.ring = static_cast<int32_t*>(
-        scratch_alloc(static_cast<size_t>(a.Nq) * vis * sizeof(int32_t), stream));
+    try {
+      args.ring = static_cast<int32_t*>(
+          scratch_alloc(static_cast<size_t>(a.Nq) * vis * sizeof(int32_t), stream));
+    }
+    catch (const Error& e) {
+      // no room for the rings (Nq x ring x 4 bytes): the ring-scan kernel needs none
+      if (e.status != GGNN_OUT_OF_MEMORY)
+        throw;
+      (void)hipGetLastError();
+      args.ring = nullptr;
+    }
   }
   struct RingGuard {
     void* p;
