@@ -1,4 +1,4 @@
-"""bf_query timing for uint8 rows: bf_time_u8.py [n=1M] [k=10] [D=128]; GGNN_BF_I8_V1=1 times the
+"""bf_query timing for uint8 rows: bf_time_u8.py [n=1M] [k=10] [D=128]; GGNN_TEST_HOOKS=1 GGNN_BF_I8_V1=1 times the
 LDS-list kernel"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """8 resident shards x 1M on one GPU: query time with the shard launches overlapped / one at a time
-(GGNN_SHARD_OVERLAP=0)"""
+(GGNN_TEST_HOOKS=1 GGNN_SHARD_OVERLAP=0: hooks are read from the environment only with the master switch)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
