@@ -287,7 +287,7 @@ def measure_point(eng, query, gt, args, steps, tau=None, iters=None, warm=2):
             "recall_at_10": recall_at_k(ids, gt)}
 
 
-SEARCH_TAUS = (0.5, 0.64, 0.8, 0.9, 1.0, 1.2, 1.5, 2.0, 2.5)
+SEARCH_TAUS = (0.5, 0.64, 0.8, 0.9, 1.0, 1.1, 1.2, 1.5, 2.0, 2.5)
 SEARCH_ITERS = (100, 175, 250, 400, 600, 800, 1000, 1500, 2000)
 
 
