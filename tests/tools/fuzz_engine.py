@@ -2,7 +2,8 @@
     python tests/tools/fuzz_engine.py [n_cases] [seed]
 Integer-valued data, squared L2: bf_query and query (on the GPU-built graph) must equal the oracle
 bit for bit, for random N, D (including rows the engine has to pad), element type, K, tau,
-iterations, pre-screen on/off."""
+iterations, pre-screen on/off, shards (all resident or swapped through fewer GPU slots), tag set
+on/off for the long visited rings."""
 import os
 import sys
 
@@ -11,6 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 import ggnn_amd as ggnn  # noqa: E402
+from ggnn_amd import _lib  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 ggnn.set_log_level(-1)
@@ -19,22 +21,28 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(n_cases):
     dtype = rng.choice(["f32", "u8"])
-    D = int(rng.choice([1, 2, 3, 4, 12, 30, 32, 64, 96, 100, 128, 130, 200, 256, 384, 960, 1024]))
+    D = int(rng.choice([1, 2, 3, 4, 12, 30, 32, 64, 68, 80, 96, 100, 128, 130, 200, 256, 384, 960, 1024]))
     N = int(rng.integers(700, 7000))
     Nq = int(rng.choice([1, 7, 64, 255, 256, 300]))
     K = int(rng.choice([1, 5, 10, 24, 50, 100, 150, 260]))
     KB = int(rng.choice([8, 16, 24, 32]))
     tau = float(rng.choice([0.3, 0.6, 0.9, 1.5]))
-    iters = int(rng.choice([50, 200, 256, 400, 600]))
+    iters = int(rng.choice([50, 200, 256, 400, 600, 800, 1200, 2000]))  # > 480: tag set (traversal.hpp)
     pre = bool(rng.integers(0, 2))
     shards = int(rng.choice([1, 1, 2, 3, 4]))
+    # out-of-core: fewer GPU slots than shards (engine.cpp SwapState); 0 = all resident
+    slots = int(rng.choice([0, 0, 1, 2])) if shards > 1 else 0
+    slots = slots if slots < shards else 0
+    tag_set = int(rng.integers(0, 4) > 0)  # mostly on (the default), sometimes the ring scan
     N = N // shards * shards
     hi = 256
     base = rng.integers(0, hi, (N, D)).astype(np.uint8 if dtype == "u8" else np.float32)
     q = rng.integers(0, hi, (Nq, D)).astype(base.dtype)
     tag = (f"case {case}: {dtype} N={N} D={D} Nq={Nq} K={K} KB={KB} tau={tau} it={iters} pre={pre} "
-           f"shards={shards}")
+           f"shards={shards} slots={slots} tag_set={tag_set}")
     try:
+        _lib.set_hook("RESIDENT_SHARDS", slots)
+        _lib.set_hook("VIS_TAG_SET", tag_set)
         eng = ggnn.GGNN()
         eng.set_base(base)
         eng.set_prescreen(pre)
