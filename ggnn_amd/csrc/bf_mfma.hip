@@ -41,6 +41,23 @@
 
 namespace ggnn_amd {
 
+// Stats build (-DGGNN_BF_PHASE, scripts/bf_phase_cycles.py): shader cycles per phase of a tile of the
+// single-chunk f32 kernel, per wave (ticks are s_memtime reads fenced against the scheduler)
+#ifdef GGNN_BF_PHASE
+static __device__ unsigned long long g_bf_phase[8];
+static __device__ const float* g_bf_dbg_bound;  // experiment: per-query bound the lists start from
+#define GGNN_BF_TICK(i)                                                  \
+  do {                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();       \
+    bf_ph[i] += t_now - bf_t;                                            \
+    bf_t = t_now;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+  } while (0)
+#else
+#define GGNN_BF_TICK(i)
+#endif
+
 // ---- 1. squared norms ---------------------------------------------------------------------------
 // SHIFT (uint8 only): norms of x - 128, the values the i8 matrix path works on; squared L2
 // distances do not change under a common shift
@@ -221,24 +238,39 @@ struct TileStage<float> {
   }
   // chunked kernel: the shift of columns [col0, col0 + CW) is read from the mean vector in LDS
   // (a global load here would sit on the critical path of every staged tile)
+  // MASKED = false: positions that were not loaded stage as 0 - shift instead of 0.  Allowed when
+  // the shift vector is zero for every staged column past D (then those products vanish with the
+  // zero query operand) -- rows past the end never matter, their distance is forced to +inf.
+  // (Measured on the single-chunk kernel: carrying `vmask` from the loads to this store costs
+  // 10 % of the whole kernel, 21.9 vs 19.7 ms; the select itself or the LDS reads alone cost
+  // nothing.)
+  template <bool MASKED = true>
   GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float* mean_lds,
                               uint32_t col0) const
   {
     if (threadIdx.x < (uint32_t)kBfTileRows)
       tile[threadIdx.x * DP + CW] = bn;
     const uint32_t cpr = CW / 4;
+    // the four shift pieces are requested together, ahead of the wait for the staged rows (one
+    // LDS round trip per tile instead of four in sequence: measured 10 % of the kernel).  The
+    // opaque zero keeps the compiler from hoisting them out of the tile loop, where they would
+    // cost 16 registers (and with them the third wave per SIMD).
+    uint32_t opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    float4 m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      m[e] = *reinterpret_cast<const float4*>(mean_lds + opaque + col0 +
+                                              4 * ((threadIdx.x + 256 * e) % cpr));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, c4 = idx % cpr;
-      if (row < (uint32_t)kBfTileRows) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vmask & (1u << e)) {
-          const float4 m = *reinterpret_cast<const float4*>(mean_lds + col0 + 4 * c4);
-          v = make_float4(r[e].x - m.x, r[e].y - m.y, r[e].z - m.z, r[e].w - m.w);
-        }
+      const bool valid = !MASKED || (vmask & (1u << e));
+      const float4 v = make_float4(valid ? r[e].x - m[e].x : 0.f, valid ? r[e].y - m[e].y : 0.f,
+                                   valid ? r[e].z - m[e].z : 0.f, valid ? r[e].w - m[e].w : 0.f);
+      if (row < (uint32_t)kBfTileRows)
         *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) = v;
-      }
     }
   }
   GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
@@ -263,6 +295,7 @@ struct TileStage<uint8_t> {
   uint4 r;
   float bn;
   GGNN_DEV void set_mean(const float*, uint32_t, uint32_t, uint32_t) {}  // bytes are not shifted
+  template <bool MASKED = true>
   GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float*, uint32_t) const
   {
     store(tile, DP, CW);
@@ -352,10 +385,18 @@ GGNN_DEV void load_query_chunk(float (&aq)[64], const uint8_t* qrow, bool qvalid
 // Rare path of the epilogue: stable insertion of the tile's distances that beat a list's worst
 // entry, candidates in ascending lane order (= ascending base index within each query row).
 // dd[r] / thr[r]: distance and threshold of register row r (query row (r&3) + 8*(r>>2) + 4*h).
-GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t row0, float* wave_d,
-                             int* wave_id, uint32_t KP, int h)
+// thr[r] of EVERY lane equals the worst entry of its query's list at all times (it is set after
+// each insertion below), so neither the test of a candidate nor the new threshold needs an LDS
+// round trip of its own: one hit = one batch of reads, one batch of writes.
+// NC: 64-entry columns of a list (KP <= 64 * NC).
+// thr_w (optional): the wave's 32 thresholds in LDS, kept equal to the lists' worst entries for
+// kernels that do not hold thr[] in registers between tiles.
+template <int NC>
+GGNN_DEV void bf_insert_hits_n(const float (&dd)[16], float (&thr)[16], uint32_t row0,
+                               float* wave_d, int* wave_id, uint32_t KP, int h, float* thr_w)
 {
   const int lane = threadIdx.x & 63;
+  const int last = static_cast<int>(KP) - 1;  // entry KP-1: lane last & 63 of column last >> 6
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     unsigned long long m = __ballot(dd[r] < thr[r]);
@@ -363,19 +404,20 @@ GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t r
       const int l = __ffsll(static_cast<long long>(m)) - 1;
       m &= m - 1;
       const float dl = rdlanef(dd[r], l);
+      // (an earlier candidate of this register row may have lowered the threshold since the ballot)
+      if (!(dl < rdlanef(thr[r], l)))
+        continue;
       const int hh = l >> 5;
       const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
       float* Ld = wave_d + qi * KP;
       int* Li = wave_id + qi * KP;
-      if (!(dl < Ld[KP - 1]))
-        continue;
       const int id = static_cast<int>(row0 + (l & 31));
-      // lane owns entries k = c*64 + lane (c < 4); stable insert: everything <= dl stays, the
-      // first larger entry becomes dl, the rest shift by one
-      float cur[4], prev[4];
-      int previ[4];
+      // lane owns entries k = c*64 + lane; stable insert: everything <= dl stays, the first larger
+      // entry becomes dl, the rest shift by one
+      float cur[NC], prev[NC];
+      int previ[NC];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int k = c * kWave + lane;
         const bool own = k < (int)KP;
         cur[c] = own ? Ld[k] : inf_f();
@@ -386,7 +428,7 @@ GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t r
       // operations of a wave execute in order); only the compiler must not reorder them
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int k = c * kWave + lane;
         if (k < (int)KP && dl < cur[c]) {
           const bool first = !(dl < prev[c]);  // previous entry stays: insert here
@@ -395,12 +437,49 @@ GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t r
         }
       }
       __builtin_amdgcn_wave_barrier();
-      // the list's new worst entry is the threshold of register row r in half-wave hh
-      const float worst = Ld[KP - 1];
+      // dl went in ahead of the old worst entry, which dropped out: the list now ends in the
+      // larger of dl and the old entry KP-2 (the `prev` of the lane that owns entry KP-1)
+      float p_last = rdlanef(prev[0], last & 63);
+      if constexpr (NC > 1) {
+        const float p1 = rdlanef(prev[NC - 1], last & 63);
+        p_last = last >= kWave ? p1 : p_last;
+      }
+#ifdef GGNN_BF_PHASE
+      const float worst = fminf(fmaxf(dl, p_last), rdlanef(thr[r], l));
+#else
+      const float worst = fmaxf(dl, p_last);
+#endif
       if (h == hh)
         thr[r] = worst;
+      if (thr_w && lane == 0)
+        thr_w[qi] = worst;
     }
   }
+}
+GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t row0, float* wave_d,
+                             int* wave_id, uint32_t KP, int h, float* thr_w = nullptr)
+{
+  static_assert(kBfMaxKP <= 2 * kWave, "lists have at most two 64-entry columns");
+  if (KP <= static_cast<uint32_t>(kWave))
+    bf_insert_hits_n<1>(dd, thr, row0, wave_d, wave_id, KP, h, thr_w);
+  else
+    bf_insert_hits_n<2>(dd, thr, row0, wave_d, wave_id, KP, h, thr_w);
+}
+
+// insertions of a tile for a kernel whose thresholds live in LDS (thr_w: the wave's 32)
+GGNN_DEV void bf_test_and_insert(const float (&dd)[16], float* thr_w, uint32_t row0, float* wave_d,
+                                 int* wave_id, uint32_t KP, int h)
+{
+  float thr[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t = *reinterpret_cast<const float4*>(thr_w + 8 * g + 4 * h);
+    thr[4 * g + 0] = t.x;
+    thr[4 * g + 1] = t.y;
+    thr[4 * g + 2] = t.z;
+    thr[4 * g + 3] = t.w;
+  }
+  bf_insert_hits(dd, thr, row0, wave_d, wave_id, KP, h, thr_w);
 }
 
 // Query operands of the chunked kernel are fetched with BUFFER loads through a descriptor that
@@ -496,7 +575,7 @@ GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
 // ahead of the MFMAs that consume them.
 template <typename BaseT, int MODE, int T, int NU>
 __global__ void __launch_bounds__(256)
-    __attribute__((amdgpu_waves_per_eu(T == 2 ? 2 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
+    __attribute__((amdgpu_waves_per_eu(T == 2 ? 2 : T == 1 ? 3 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   // the two tile buffers are addressed as lds_f + offset (never through a pointer array: a select
@@ -509,15 +588,60 @@ __global__ void __launch_bounds__(256)
   float* list_d = lds_f + 2 * tile_floats;
   int* list_id = reinterpret_cast<int*>(list_d + kBfQueriesPerBlock * a.KP);
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: keep it in an SGPR
   const int j = lane & 31, h = lane >> 5;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
-  const uint32_t qbase = (blockIdx.x * 4 + wave) * 32;
-  const uint32_t begin = blockIdx.y * a.rows_per_slice;
-  const uint32_t end = min(a.N_base, begin + a.rows_per_slice);
   const uint32_t KP = a.KP;
   const uint32_t nch = (a.D + CW - 1) / CW;
+  float aq[64];
+  // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
+  // squared norm standing in for rows past the end of the slice: +inf distance for L2
+  const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
+  TileStage<BaseT> stage;
+  stage.set_mean(nullptr, a.D, 0, CW);
+  // behind the candidate lists: the shift vector (a.DM floats), and for the single-chunk kernel
+  // the 128 query norms and the 128 thresholds = worst list entries (nothing beats -inf:
+  // padding queries).  In LDS, not in registers: 48 registers less is what lets a THIRD
+  // workgroup share the CU, and three waves per SIMD cover each other's insertions and barriers.
+  float* mean_lds = reinterpret_cast<float*>(list_id + kBfQueriesPerBlock * a.KP);
+  float* qn_lds = mean_lds + a.DM;
+  float* thr_lds = qn_lds + kBfQueriesPerBlock;
+  for (uint32_t i = tid; i < a.DM; i += 256)
+    mean_lds[i] = (a.mean && i < a.D) ? a.mean[i] : 0.f;
+
+  // Work of this workgroup.  Chunked kernel: query block blockIdx.x, base slice blockIdx.y.
+  // Single-chunk kernel: the (query block, tile) pairs form ONE sequence of Nq/128 * N/32 tiles that
+  // is cut into gridDim.x equal ranges (a.tiles_per_block), so every resident workgroup gets the
+  // same amount of work whatever Nq is; a range that crosses a query-block boundary is processed
+  // as two (or more) segments, each with fresh lists written to its own part.
+  uint64_t work = 0, work_end = 0;
+  if constexpr (T == 1) {
+    work = static_cast<uint64_t>(blockIdx.x) * a.tiles_per_block;
+    work_end = min(a.total_tiles, work + a.tiles_per_block);
+  }
+  do {
+  uint32_t qblock = blockIdx.x, begin = 0, end = 0, part = blockIdx.y;
+  if constexpr (T == 1) {
+    if (work >= work_end)
+      break;
+    qblock = static_cast<uint32_t>(work / a.tiles_per_q);
+    const uint64_t q_first = static_cast<uint64_t>(qblock) * a.tiles_per_q;
+    const uint32_t t0 = static_cast<uint32_t>(work - q_first);
+    const uint32_t cnt =
+        static_cast<uint32_t>(min(static_cast<uint64_t>(a.tiles_per_q - t0), work_end - work));
+    begin = t0 * kBfTileRows;
+    end = min(a.N_base, (t0 + cnt) * kBfTileRows);
+    // parts of a query block are numbered from the first workgroup that touches it
+    part = blockIdx.x - static_cast<uint32_t>(q_first / a.tiles_per_block);
+    work += cnt;
+  }
+  else {
+    begin = blockIdx.y * a.rows_per_slice;
+    end = min(a.N_base, begin + a.rows_per_slice);
+  }
+  const uint32_t qbase = (qblock * 4 + wave) * 32;
 
   // candidate lists of this wave's 32 queries; padding queries get -inf so that nothing ever
   // beats their threshold (their lists are never written out)
@@ -525,34 +649,21 @@ __global__ void __launch_bounds__(256)
     list_d[wave * 32 * KP + i] = (qbase + i / KP < a.Nq) ? inf_f() : -inf_f();
     list_id[wave * 32 * KP + i] = kEmptyKey;
   }
-
   const bool qvalid = qbase + j < a.Nq;
   const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
-  float aq[64];
-  // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
-  // single-chunk path: query norms and thr[r], the worst entry of the candidate list of query row
-  // i(r), stay in registers (nothing beats -inf: padding); the chunked path fetches them per group
-  float qn[16], thr[16];
   if constexpr (T == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const uint32_t qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-      qn[r] = qi < a.Nq ? a.qnorm[qi] : 0.f;
-      thr[r] = qi < a.Nq ? inf_f() : -inf_f();
+    if (lane < 32) {  // this wave's entries only: nothing to order against the other waves
+      const uint32_t qi = qbase + lane;
+      qn_lds[wave * 32 + lane] = qi < a.Nq ? a.qnorm[qi] : 0.f;
+      float t0v = qi < a.Nq ? inf_f() : -inf_f();
+#ifdef GGNN_BF_PHASE
+      if (g_bf_dbg_bound && qi < a.Nq)
+        t0v = g_bf_dbg_bound[qi];
+#endif
+      thr_lds[wave * 32 + lane] = t0v;
     }
   }
-
-  // squared norm standing in for rows past the end of the slice: +inf distance for L2
-  const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
-  TileStage<BaseT> stage;
-  stage.set_mean(T == 1 ? a.mean : nullptr, a.D, 0, CW);
-  // chunked kernel: the whole shift vector sits behind the candidate lists in LDS
-  float* mean_lds = reinterpret_cast<float*>(list_id + kBfQueriesPerBlock * a.KP);
-  if constexpr (T > 1) {
-    for (uint32_t i = tid; i < a.DM; i += 256)
-      mean_lds[i] = (a.mean && i < a.D) ? a.mean[i] : 0.f;
-    __syncthreads();
-  }
+  __syncthreads();
   const uint32_t ntiles = (end > begin) ? (end - begin + kBfTileRows - 1) / kBfTileRows : 0;
   if (ntiles) {
     if constexpr (T > 1) {
@@ -561,27 +672,28 @@ __global__ void __launch_bounds__(256)
     }
     else {
       stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
-      stage.store(lds_f, DP, CW);
+      stage.template store_shifted<false>(lds_f, DP, CW, mean_lds, 0);
     }
   }
   __syncthreads();
 
   if constexpr (T == 1) {
-    // One chunk per row (D <= 128): the epilogue of tile t-1 is interleaved with the MFMA chain
-    // of tile t -- its 16 x (add, fma, compare) are independent of the running accumulator, so
-    // the matrix pipe does not drain between tiles.  Before the first tile the "previous"
-    // accumulator is a dummy whose distances are +inf.
+    // One chunk per row (D <= 128).  The test of a tile follows its own MFMA chain (no software
+    // pipeline over tiles: a second accumulator set would cost the third wave per SIMD, and it
+    // is the other two waves of the SIMD that keep the matrix pipe busy meanwhile).
     load_query_chunk(aq, qrow, qvalid, a.D, Dh, h * Dh);
-    f32x16 acc_prev = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bn_prev = bn_pad;
-    bool jvalid_prev = false;
-    uint32_t row0_prev = begin;
     float* wave_d = list_d + wave * 32 * KP;
     int* wave_id = list_id + wave * 32 * KP;
-    // Everything loaded so far (query chunk, query norms) must have arrived BEFORE the loop: a
-    // first use inside the loop makes the compiler wait for vmcnt(0) in every iteration, which
-    // also waits for the prefetch of the next tile issued just before (s_waitcnt vmcnt(0)).
+    const float* qn_w = qn_lds + wave * 32;
+    float* thr_w = thr_lds + wave * 32;
+    // Everything loaded so far (the query chunk) must have arrived BEFORE the loop: a first use
+    // inside the loop makes the compiler wait for vmcnt(0) in every iteration, which also waits
+    // for the prefetch of the next tile issued just before (s_waitcnt vmcnt(0)).
     __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef GGNN_BF_PHASE
+    unsigned long long bf_ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long bf_t = __builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t tt = 0; tt < ntiles; ++tt) {
       const uint32_t row0 = begin + tt * kBfTileRows;
       const bool jvalid = row0 + j < end;
@@ -593,41 +705,45 @@ __global__ void __launch_bounds__(256)
         stage.load(base, a.D, row0 + kBfTileRows, end, 0, CW, a.bnorm, bn_pad);
       f32x16 acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float* bt = lds_f + (tt & 1) * tile_floats + j * DP + h * Dh;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc, 0, 0, 0);
+      }
       float dd[16];
       unsigned long long any = 0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (u < NU) {
-          const float4 bv = *reinterpret_cast<const float4*>(bt + 4 * u);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 0], bv.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 1], bv.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 2], bv.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[4 * u + 3], bv.w, acc, 0, 0, 0);
-        }
-        dd[u] = bf_expand<MODE>(acc_prev[u], qn[u], bn_prev, jvalid_prev);
-        any |= __ballot(dd[u] < thr[u]);
+      for (int g = 0; g < 4; ++g) {
+        const float4 qn4 = *reinterpret_cast<const float4*>(qn_w + 8 * g + 4 * h);
+        const float4 th4 = *reinterpret_cast<const float4*>(thr_w + 8 * g + 4 * h);
+        dd[4 * g + 0] = bf_expand<MODE>(acc[4 * g + 0], qn4.x, bn, jvalid);
+        dd[4 * g + 1] = bf_expand<MODE>(acc[4 * g + 1], qn4.y, bn, jvalid);
+        dd[4 * g + 2] = bf_expand<MODE>(acc[4 * g + 2], qn4.z, bn, jvalid);
+        dd[4 * g + 3] = bf_expand<MODE>(acc[4 * g + 3], qn4.w, bn, jvalid);
+        any |= __ballot(dd[4 * g + 0] < th4.x) | __ballot(dd[4 * g + 1] < th4.y) |
+               __ballot(dd[4 * g + 2] < th4.z) | __ballot(dd[4 * g + 3] < th4.w);
       }
+      GGNN_BF_TICK(0);
       if (any)
-        bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+        bf_test_and_insert(dd, thr_w, row0, wave_d, wave_id, KP, h);
+      GGNN_BF_TICK(1);
       if (has_next)
-        stage.store(lds_f + ((tt + 1) & 1) * tile_floats, DP, CW);
+        stage.template store_shifted<false>(lds_f + ((tt + 1) & 1) * tile_floats, DP, CW, mean_lds,
+                                            0);
+      GGNN_BF_TICK(2);
       __syncthreads();
-      acc_prev = acc;
-      bn_prev = bn;
-      jvalid_prev = jvalid;
-      row0_prev = row0;
+      GGNN_BF_TICK(3);
     }
-    if (ntiles) {
-      float dd[16];
-      unsigned long long any = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dd[r] = bf_expand<MODE>(acc_prev[r], qn[r], bn_prev, jvalid_prev);
-        any |= __ballot(dd[r] < thr[r]);
-      }
-      if (any)
-        bf_insert_hits(dd, thr, row0_prev, wave_d, wave_id, KP, h);
+#ifdef GGNN_BF_PHASE
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i)
+        atomicAdd(&g_bf_phase[i], bf_ph[i]);
+      atomicAdd(&g_bf_phase[4], static_cast<unsigned long long>(ntiles));
     }
+#endif
   }
   else {
   // this workgroup's 128 query rows as a buffer window (rows past Nq are out of range: zero)
@@ -734,15 +850,16 @@ __global__ void __launch_bounds__(256)
   }
   }  // T > 1
 
-  // partial results of this base slice
+  // partial results of this base slice / segment
   for (uint32_t i = lane; i < 32 * KP; i += 64) {
     const uint32_t qi = qbase + i / KP;
     if (qi < a.Nq) {
-      const size_t o = (static_cast<size_t>(blockIdx.y) * a.Nq + qi) * KP + i % KP;
+      const size_t o = (static_cast<size_t>(part) * a.Nq + qi) * KP + i % KP;
       a.part_ids[o] = list_id[wave * 32 * KP + i];
       a.part_dists[o] = list_d[wave * 32 * KP + i];
     }
   }
+  } while (T == 1);
 }
 
 // ---- 2b. uint8 rows, squared L2: the contraction on v_mfma_i32_32x32x32_i8 ------------------------
@@ -1012,7 +1129,7 @@ bool bf_mfma_supported(const BfLaunch& a)
   // tiles + candidate lists (+ the shift vector of the chunked kernel) must fit into 160 KB of LDS
   const size_t lists = 2ull * kBfQueriesPerBlock * (a.k_query + 8);
   const size_t tiles = 2ull * kBfTileRows * 132;
-  const size_t shift = a.D > 128 ? (a.D + 3) / 4 * 4 : 0;
+  const size_t shift = a.D > 128 ? (a.D + 3) / 4 * 4 : 128 + 2 * kBfQueriesPerBlock;
   return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
@@ -1045,12 +1162,39 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   // one round of resident workgroups (2 per CU x 256 CUs at this register budget): a partial
   // second round costs more than the lower parallelism (measured: 790 blocks 39.8 ms, 474 blocks
   // 31.5 ms for 10k x 1M x 128)
-  uint32_t slices = std::max(1u, std::min(32u, 512u / std::max(1u, qblocks)));
+  // (the single-chunk float kernel runs three workgroups per CU when their LDS fits)
+  const bool single_chunk = !use_i8 && a.D <= 128;
+  uint32_t resident = 512;
+  if (single_chunk) {
+    const size_t lds1 = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + 2 * Dh +
+                         2 * kBfQueriesPerBlock) * sizeof(float);
+    resident = 256u * static_cast<uint32_t>(std::clamp<size_t>(160 * 1024 / lds1, 1, 3));
+  }
+  uint32_t slices = std::max(1u, std::min(32u, resident / std::max(1u, qblocks)));
   if (const int64_t hs = hook(kHookBfSlices); hs > 0)  // tuning hook
     slices = static_cast<uint32_t>(std::clamp<int64_t>(hs, 1, 64));
   uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
+  // single-chunk float kernel: Nq/128 * N/32 (query block, tile) pairs in one sequence, cut into
+  // `resident` equal ranges -- every workgroup slot of the chip gets the same work whatever Nq is
+  // (79 query blocks x 9 slices left 7 % of the slots empty).  A query block then has up to
+  // ceil(tiles_per_q / range) + 1 parts; ranges are at least 1/32 of a query block (the lists of
+  // every part start empty, and what they accept before their thresholds settle is the cost).
+  // Hook BF_SLICES: ranges of 1/BF_SLICES of a query block, i.e. the aligned slices of old.
+  const uint32_t tiles_per_q = (a.N_base + kBfTileRows - 1) / kBfTileRows;
+  const uint64_t total_tiles = static_cast<uint64_t>(qblocks) * tiles_per_q;
+  uint32_t tiles_per_block = 0, nblocks = 0;
+  if (single_chunk) {
+    uint64_t per = (total_tiles + resident - 1) / resident;
+    per = std::max<uint64_t>(per, (tiles_per_q + 31) / 32);
+    if (const int64_t hs = hook(kHookBfSlices); hs > 0)
+      per = (tiles_per_q + slices - 1) / slices;
+    per = std::clamp<uint64_t>(per, 1, 0xffffffffu);
+    tiles_per_block = static_cast<uint32_t>(per);
+    nblocks = static_cast<uint32_t>((total_tiles + per - 1) / per);
+    slices = (tiles_per_q + tiles_per_block - 1) / tiles_per_block + 1;  // parts per query
+  }
 
   // float32 squared L2: rows are shifted by a column mean of the base (hook BF_NO_CENTER = 1: test
   // hook that leaves them unshifted so that offset data exercises the re-scan)
@@ -1091,6 +1235,12 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   if (use_i8v2)  // +inf
     GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7f800000, a.Nq,
                                      stream));
+  if (single_chunk) {
+    // not every query block has all `slices` parts: the others read as empty lists
+    GGNN_HIP_CHECK(hipMemsetAsync(part_ids, 0xff, parts * sizeof(int32_t), stream));
+    GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(part_dists), 0x7f800000,
+                                     parts, stream));
+  }
 
   if (center) {
     // at most ~32k evenly spaced rows: plenty for a shift, negligible next to the scan itself
@@ -1126,8 +1276,14 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   m.KP = KP;
   m.slices = slices;
   m.rows_per_slice = rows_per_slice;
-  m.DM = a.D > 128 ? (a.D + 3) / 4 * 4 : 0;  // the chunked kernel keeps the shift vector in LDS
-  const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM) * sizeof(float);
+  m.tiles_per_q = tiles_per_q;
+  m.tiles_per_block = tiles_per_block;
+  m.total_tiles = total_tiles;
+  // the shift vector sits in LDS (single chunk: its 2*Dh columns; 128 query norms and 128
+  // thresholds follow)
+  m.DM = a.D > 128 ? (a.D + 3) / 4 * 4 : 2 * Dh;
+  const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM +
+                      (a.D > 128 ? 0 : 2 * kBfQueriesPerBlock)) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
   // rows longer than one chunk: base tiles per accumulator group (hook BF_TILES = 2 | 4)
   const int tiles_per_group = hook(kHookBfTiles) == 4 ? 4 : 2;
@@ -1169,7 +1325,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
       GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                          static_cast<int>(lds)));                                 \
     void* kargs[] = {&m};                                                                         \
-    GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds, stream));  \
+    const dim3 grid = single_chunk ? dim3(nblocks) : dim3(qblocks, slices);                       \
+    GGNN_HIP_CHECK(hipLaunchKernel(kern, grid, dim3(256), kargs, lds, stream));                   \
   } while (0)
   if (use_i8) {
     hipLaunchKernelGGL((row_norms_kernel<uint8_t, true>),
@@ -1240,3 +1397,23 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
 }
 
 }  // namespace ggnn_amd
+
+#ifdef GGNN_BF_PHASE
+extern "C" int ggnn_debug_bf_bound(const float* bound)
+{
+  using namespace ggnn_amd;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bf_dbg_bound), &bound, sizeof(bound)) != hipSuccess;
+}
+extern "C" int ggnn_debug_bf_phase(unsigned long long* out8, int reset)
+{
+  using namespace ggnn_amd;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bf_phase), 8 * sizeof(unsigned long long)) != hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bf_phase), z, sizeof(z)) != hipSuccess)
+      return 1;
+  }
+  return 0;
+}
+#endif

@@ -198,6 +198,34 @@ def test_bf_mfma_odd_sizes(ops, orc, N, Nq, K, D):
     check_against_float64(base, q, ids.cpu().numpy(), K, 0)
 
 
+@pytest.mark.parametrize("N,Nq,D,slices", [
+    (4100, 110_000, 32, 0),    # 860 query blocks > resident workgroups: ranges span several blocks
+    (4100, 40_000, 64, 0),     # a range = a bit more than one query block
+    (100_000, 1000, 128, 0),   # ranges floored at 1/32 of a query block
+    (30_000, 1500, 96, 7),     # hook: ranges of 1/7 of a query block (not a multiple of the tiles)
+    (30_000, 1500, 128, 1),    # hook: one range per query block
+])
+def test_bf_mfma_equal_tile_ranges(ops, N, Nq, D, slices):
+    """the single-chunk kernel cuts the (query block, tile) sequence into equal ranges; a range that
+    crosses query-block boundaries is processed in segments with fresh lists, and query blocks have
+    different numbers of parts (bf_mfma.hip, "Work of this workgroup"): results must equal the scan
+    kernel's, bit for bit, for every way the ranges fall"""
+    from ggnn_amd import _lib
+    base = make_int_data(N, D, 901)
+    q = make_int_data(Nq, D, 902)
+    b, qq = dev(base), dev(q)
+    with _lib.hooks(**({"BF_SLICES": slices} if slices else {})):
+        ids, dists, resc = ops.bf_query(b, qq, 10, 0, rescanned=True)
+    # scan kernel in batches (it is the path for < 256 queries)
+    sel = np.unique(np.concatenate([np.arange(0, Nq, max(1, Nq // 600)), np.arange(Nq - 130, Nq),
+                                    np.arange(120, 140)]))
+    sub = dev(q[sel])
+    s_ids = torch.cat([ops.bf_query(b, sub[i:i + 200].contiguous(), 10, 0)[0] for i in range(0, len(sel), 200)])
+    s_d = torch.cat([ops.bf_query(b, sub[i:i + 200].contiguous(), 10, 0)[1] for i in range(0, len(sel), 200)])
+    t = torch.from_numpy(sel).cuda()
+    assert torch.equal(ids[t], s_ids) and torch.equal(dists[t], s_d)
+
+
 @pytest.mark.parametrize("N,D,Nq,K", [(50_000, 128, 700, 10), (33_333, 128, 257, 3), (20_001, 96, 300, 16),
                                       (9_000, 64, 513, 10), (4_100, 32, 256, 4), (70_000, 128, 1000, 1)])
 def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
