@@ -366,7 +366,7 @@ def bf_block(args, bf_ms, rescanned):
                               F32_MFMA_PEAK, "TFLOP/s")
     return {"ms": bf_ms, "kernel": kernel, "rate": ops_ / (bf_ms * 1e-3) / 1e12, "unit": unit,
             "peak": peak / 1e12, "mfma_frac_of_peak": ops_ / (bf_ms * 1e-3) / peak,
-            "note": "end to end (norms, tile kernel, re-rank / certificate)",
+            "note": "end to end (norms, tile kernel, re-rank / certificate), second call",
             "queries_rescanned_by_the_exact_scan": rescanned}
 
 
@@ -573,6 +573,8 @@ def run_single(args, device, ggnn):
 
     # ground truth by exact brute force on the same data (untimed)
     gt, _ = eng.bf_query(query, args.k, measure)
+    # its time is reported from a second call: the first one also grows the scratch pool
+    eng.bf_query(query, args.k, measure)
     bf_ms = eng.last_timing_ms()["bf_query_ms"]
     bf_rescanned = eng.last_bf_query_rescanned()
 

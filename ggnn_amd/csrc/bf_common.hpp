@@ -22,8 +22,10 @@ struct BfMfmaArgs {
   uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
   uint32_t DM;  // floats of the shift vector kept in LDS by the chunked kernel (D rounded up)
   uint32_t* gthr;  // i8 v2 kernel: per-query bound shared by all slices (float bits), or null
-  // single-chunk float kernel: the (query block, 32-row tile) sequence is cut into equal ranges
-  uint32_t tiles_per_q;      // ceil(N_base / 32)
+  // float tile kernels, equal_ranges != 0: the (query block, unit) sequence is cut into equal
+  // ranges, a unit being 32 rows (single chunk) or one accumulator group of T x 32 rows (chunked)
+  uint32_t equal_ranges;
+  uint32_t tiles_per_q;      // units per query block
   uint32_t tiles_per_block;  // range of one workgroup
   uint64_t total_tiles;      // query blocks * tiles_per_q
 };

@@ -201,60 +201,43 @@ struct TileStage;
 template <>
 struct TileStage<float> {
   float4 r[4];
-  float4 mu[4];  // shift of this thread's columns (single-chunk kernel; zero without centring)
-  uint32_t vmask;  // bit e: r[e] holds row data (chunked kernel: the shift comes from LDS)
-  float bn;  // threads 0..31: squared norm of tile row threadIdx.x (pad value past the end)
-  // columns [col0, col0 + CW) are staged next; the single-chunk kernel calls this once
-  GGNN_DEV void set_mean(const float* mean, uint32_t D, uint32_t col0, uint32_t CW)
-  {
-    const uint32_t cpr = CW / 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t col = col0 + 4 * ((threadIdx.x + 256 * e) % cpr);
-      mu[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mean && col < D)
-        mu[e] = *reinterpret_cast<const float4*>(mean + col);
-    }
-  }
+  float bn;          // squared norm of tile row threadIdx.x & 31
+  uint32_t rows;     // rows of the staged tile that exist (the others get bn_pad)
+  float bn_pad;
+  // Every lane loads, unconditionally and without initialising its registers first: rows past
+  // `end` re-read the last row of the range and columns past D the row's last four -- finite
+  // values that never matter (such a row gets the +inf / invalid norm at the store, and the query
+  // operand is zero in such a column).  A predicated load needs `r = 0` in front of it, and a
+  // VALU write to a register that a load of the previous tile targeted makes the compiler wait for
+  // vmcnt(0) at the top of the tile loop -- i.e. for every query piece the chunked kernel had
+  // just prefetched (222 -> 165 ms at D = 960 when this wait was found).
   GGNN_DEV void load(const float* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
-                     uint32_t CW, const float* bnorm, float bn_pad)
+                     uint32_t CW, const float* bnorm, float bn_pad_)
   {
-    bn = bn_pad;
-    if (threadIdx.x < (uint32_t)kBfTileRows && row0 + threadIdx.x < end)
-      bn = bnorm[row0 + threadIdx.x];
+    const uint32_t last = end - 1;  // (end > 0; row0 >= end: a group's padding tile, no valid row)
+    rows = end > row0 ? end - row0 : 0u;
+    bn_pad = bn_pad_;
+    bn = bnorm[min(row0 + (threadIdx.x & 31u), last)];
     const uint32_t cpr = CW / 4;
-    vmask = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, col = col0 + 4 * (idx % cpr);
-      // (predicated load on purpose: the clamped-address + select form measured 30 % slower)
-      r[e] = mu[e];  // rows / columns past the end stage as zero after the shift
-      if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D) {
-        r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(row0 + row) * D + col);
-        vmask |= 1u << e;
-      }
+      r[e] = *reinterpret_cast<const float4*>(base + static_cast<size_t>(min(row0 + row, last)) * D +
+                                              min(col, D - 4));
     }
   }
-  // chunked kernel: the shift of columns [col0, col0 + CW) is read from the mean vector in LDS
-  // (a global load here would sit on the critical path of every staged tile)
-  // MASKED = false: positions that were not loaded stage as 0 - shift instead of 0.  Allowed when
-  // the shift vector is zero for every staged column past D (then those products vanish with the
-  // zero query operand) -- rows past the end never matter, their distance is forced to +inf.
-  // (Measured on the single-chunk kernel: carrying `vmask` from the loads to this store costs
-  // 10 % of the whole kernel, 21.9 vs 19.7 ms; the select itself or the LDS reads alone cost
-  // nothing.)
-  template <bool MASKED = true>
+  // the shift of columns [col0, col0 + CW) is read from the shift vector in LDS, which is zero
+  // past column D (so that the clamped columns stay finite)
   GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float* mean_lds,
                               uint32_t col0) const
   {
     if (threadIdx.x < (uint32_t)kBfTileRows)
-      tile[threadIdx.x * DP + CW] = bn;
+      tile[threadIdx.x * DP + CW] = threadIdx.x < rows ? bn : bn_pad;
     const uint32_t cpr = CW / 4;
-    // the four shift pieces are requested together, ahead of the wait for the staged rows (one
-    // LDS round trip per tile instead of four in sequence: measured 10 % of the kernel).  The
+    // the four shift pieces are requested together, ahead of the wait for the staged rows.  The
     // opaque zero keeps the compiler from hoisting them out of the tile loop, where they would
-    // cost 16 registers (and with them the third wave per SIMD).
+    // cost 16 registers (and with them the third wave per SIMD of the single-chunk kernel).
     uint32_t opaque = 0;
     asm volatile("" : "+v"(opaque));
     float4 m[4];
@@ -266,56 +249,37 @@ struct TileStage<float> {
     for (int e = 0; e < 4; ++e) {
       const uint32_t idx = threadIdx.x + 256 * e;
       const uint32_t row = idx / cpr, c4 = idx % cpr;
-      const bool valid = !MASKED || (vmask & (1u << e));
-      const float4 v = make_float4(valid ? r[e].x - m[e].x : 0.f, valid ? r[e].y - m[e].y : 0.f,
-                                   valid ? r[e].z - m[e].z : 0.f, valid ? r[e].w - m[e].w : 0.f);
-      if (row < (uint32_t)kBfTileRows)
-        *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) = v;
-    }
-  }
-  GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
-  {
-    if (threadIdx.x < (uint32_t)kBfTileRows)
-      tile[threadIdx.x * DP + CW] = bn;  // spare column behind the chunk (DP >= CW + 4)
-    const uint32_t cpr = CW / 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t idx = threadIdx.x + 256 * e;
-      const uint32_t row = idx / cpr, c4 = idx % cpr;
       if (row < (uint32_t)kBfTileRows)
         *reinterpret_cast<float4*>(tile + row * DP + 4 * c4) =
-            make_float4(r[e].x - mu[e].x, r[e].y - mu[e].y, r[e].z - mu[e].z, r[e].w - mu[e].w);
+            make_float4(r[e].x - m[e].x, r[e].y - m[e].y, r[e].z - m[e].z, r[e].w - m[e].w);
     }
   }
 };
 
 // u8: CW/16 chunks of 16 bytes per row, 32 rows -> at most 256 chunks, one per thread
+// (unconditional clamped loads as above)
 template <>
 struct TileStage<uint8_t> {
   uint4 r;
   float bn;
-  GGNN_DEV void set_mean(const float*, uint32_t, uint32_t, uint32_t) {}  // bytes are not shifted
-  template <bool MASKED = true>
-  GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float*, uint32_t) const
-  {
-    store(tile, DP, CW);
-  }
+  uint32_t rows;
+  float bn_pad;
   GGNN_DEV void load(const uint8_t* base, uint32_t D, uint32_t row0, uint32_t end, uint32_t col0,
-                     uint32_t CW, const float* bnorm, float bn_pad)
+                     uint32_t CW, const float* bnorm, float bn_pad_)
   {
-    bn = bn_pad;
-    if (threadIdx.x < (uint32_t)kBfTileRows && row0 + threadIdx.x < end)
-      bn = bnorm[row0 + threadIdx.x];
+    const uint32_t last = end - 1;
+    rows = end > row0 ? end - row0 : 0u;
+    bn_pad = bn_pad_;
+    bn = bnorm[min(row0 + (threadIdx.x & 31u), last)];
     const uint32_t cpr = CW / 16;
     const uint32_t row = threadIdx.x / cpr, col = col0 + 16 * (threadIdx.x % cpr);
-    r = make_uint4(0u, 0u, 0u, 0u);
-    if (row < (uint32_t)kBfTileRows && row0 + row < end && col < D)
-      r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row0 + row) * D + col);
+    r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(min(row0 + row, last)) * D +
+                                        min(col, D - 16));
   }
-  GGNN_DEV void store(float* tile, uint32_t DP, uint32_t CW) const
+  GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float*, uint32_t) const
   {
     if (threadIdx.x < (uint32_t)kBfTileRows)
-      tile[threadIdx.x * DP + CW] = bn;
+      tile[threadIdx.x * DP + CW] = threadIdx.x < rows ? bn : bn_pad;
     const uint32_t cpr = CW / 16;
     const uint32_t row = threadIdx.x / cpr, c = threadIdx.x % cpr;
     if (row < (uint32_t)kBfTileRows) {
@@ -414,16 +378,19 @@ GGNN_DEV void bf_insert_hits_n(const float (&dd)[16], float (&thr)[16], uint32_t
       const int id = static_cast<int>(row0 + (l & 31));
       // lane owns entries k = c*64 + lane; stable insert: everything <= dl stays, the first larger
       // entry becomes dl, the rest shift by one
+      // (reads are unconditional -- lanes past the list's end, and lane 0's "previous" entry, read
+      // neighbouring LDS words that are never used: a predicated read is an exec-mask region of
+      // its own, and this path is a serial chain whose length is what an insertion costs)
       float cur[NC], prev[NC];
       int previ[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int k = c * kWave + lane;
-        const bool own = k < (int)KP;
-        cur[c] = own ? Ld[k] : inf_f();
-        prev[c] = (own && k > 0) ? Ld[k - 1] : -inf_f();
-        previ[c] = (own && k > 0) ? Li[k - 1] : kEmptyKey;
+        cur[c] = Ld[k];
+        prev[c] = Ld[k - 1];
+        previ[c] = Li[k - 1];
       }
+      prev[0] = lane == 0 ? -inf_f() : prev[0];  // entry 0 has no predecessor: dl goes there
       // one wave: the loads above are issued for all lanes before the stores below (LDS
       // operations of a wave execute in order); only the compiler must not reorder them
       __builtin_amdgcn_wave_barrier();
@@ -451,9 +418,14 @@ GGNN_DEV void bf_insert_hits_n(const float (&dd)[16], float (&thr)[16], uint32_t
 #endif
       if (h == hh)
         thr[r] = worst;
-      if (thr_w && lane == 0)
-        thr_w[qi] = worst;
     }
+  }
+  // the LDS copy of the thresholds: lanes 0 and 32 hold the 16 of their half-wave's query rows
+  if (thr_w && (lane & 31) == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(thr_w + 8 * g + 4 * h) =
+          make_float4(thr[4 * g + 0], thr[4 * g + 1], thr[4 * g + 2], thr[4 * g + 3]);
   }
 }
 GGNN_DEV void bf_insert_hits(const float (&dd)[16], float (&thr)[16], uint32_t row0, float* wave_d,
@@ -600,7 +572,6 @@ __global__ void __launch_bounds__(256)
   // squared norm standing in for rows past the end of the slice: +inf distance for L2
   const float bn_pad = (MODE == kL2) ? inf_f() : 0.f;
   TileStage<BaseT> stage;
-  stage.set_mean(nullptr, a.D, 0, CW);
   // behind the candidate lists: the shift vector (a.DM floats), and for the single-chunk kernel
   // the 128 query norms and the 128 thresholds = worst list entries (nothing beats -inf:
   // padding queries).  In LDS, not in registers: 48 registers less is what lets a THIRD
@@ -611,19 +582,21 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = tid; i < a.DM; i += 256)
     mean_lds[i] = (a.mean && i < a.D) ? a.mean[i] : 0.f;
 
-  // Work of this workgroup.  Chunked kernel: query block blockIdx.x, base slice blockIdx.y.
-  // Single-chunk kernel: the (query block, tile) pairs form ONE sequence of Nq/128 * N/32 tiles that
-  // is cut into gridDim.x equal ranges (a.tiles_per_block), so every resident workgroup gets the
-  // same amount of work whatever Nq is; a range that crosses a query-block boundary is processed
-  // as two (or more) segments, each with fresh lists written to its own part.
+  // Work of this workgroup.  a.equal_ranges: the (query block, unit) pairs -- a unit = T tiles, one
+  // accumulator group -- form ONE sequence of Nq/128 * N/(32 T) units that is cut into gridDim.x
+  // equal ranges (a.tiles_per_block), so every resident workgroup gets the same amount of work
+  // whatever Nq is; a range that crosses a query-block boundary is processed as two (or more)
+  // segments, each with fresh lists written to its own part.  Otherwise (the i8 kernels' launch geometry):
+  // query block blockIdx.x, base slice blockIdx.y.
+  constexpr uint32_t kUnitRows = kBfTileRows * T;
   uint64_t work = 0, work_end = 0;
-  if constexpr (T == 1) {
+  if (a.equal_ranges) {
     work = static_cast<uint64_t>(blockIdx.x) * a.tiles_per_block;
     work_end = min(a.total_tiles, work + a.tiles_per_block);
   }
   do {
   uint32_t qblock = blockIdx.x, begin = 0, end = 0, part = blockIdx.y;
-  if constexpr (T == 1) {
+  if (a.equal_ranges) {
     if (work >= work_end)
       break;
     qblock = static_cast<uint32_t>(work / a.tiles_per_q);
@@ -631,8 +604,8 @@ __global__ void __launch_bounds__(256)
     const uint32_t t0 = static_cast<uint32_t>(work - q_first);
     const uint32_t cnt =
         static_cast<uint32_t>(min(static_cast<uint64_t>(a.tiles_per_q - t0), work_end - work));
-    begin = t0 * kBfTileRows;
-    end = min(a.N_base, (t0 + cnt) * kBfTileRows);
+    begin = t0 * kUnitRows;
+    end = min(a.N_base, (t0 + cnt) * kUnitRows);
     // parts of a query block are numbered from the first workgroup that touches it
     part = blockIdx.x - static_cast<uint32_t>(q_first / a.tiles_per_block);
     work += cnt;
@@ -672,7 +645,7 @@ __global__ void __launch_bounds__(256)
     }
     else {
       stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
-      stage.template store_shifted<false>(lds_f, DP, CW, mean_lds, 0);
+      stage.store_shifted(lds_f, DP, CW, mean_lds, 0);
     }
   }
   __syncthreads();
@@ -731,7 +704,7 @@ __global__ void __launch_bounds__(256)
         bf_test_and_insert(dd, thr_w, row0, wave_d, wave_id, KP, h);
       GGNN_BF_TICK(1);
       if (has_next)
-        stage.template store_shifted<false>(lds_f + ((tt + 1) & 1) * tile_floats, DP, CW, mean_lds,
+        stage.store_shifted(lds_f + ((tt + 1) & 1) * tile_floats, DP, CW, mean_lds,
                                             0);
       GGNN_BF_TICK(2);
       __syncthreads();
@@ -748,8 +721,25 @@ __global__ void __launch_bounds__(256)
   else {
   // this workgroup's 128 query rows as a buffer window (rows past Nq are out of range: zero)
   QueryWindow<BaseT> qw;
-  qw.open(query, a.Nq, a.D, blockIdx.x * kBfQueriesPerBlock, wave * 32 + j);
+  qw.open(query, a.Nq, a.D, qblock * kBfQueriesPerBlock, wave * 32 + j);
   uint32_t p = 0;  // (tile, chunk) pairs processed: buffer p&1 holds the current pair
+#ifdef GGNN_BF_PHASE
+  unsigned long long bf_ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long bf_t = __builtin_amdgcn_s_memtime();
+#endif
+  // The first query chunk is loaded here, every later one during the last tile of the chunk
+  // before it (mfma_chain<PREFETCH>).  NOT inside the loops under `if (first)`: the operand
+  // registers would then be a phi of two load sites, which the compiler resolves with 64 copies and
+  // a wait for vmcnt(0) at the top of every (group, chunk) iteration -- right behind the sixteen
+  // loads the prefetch had just issued.
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float4 v = qw.piece(h * Dh, t);
+    aq[4 * t + 0] = v.x;
+    aq[4 * t + 1] = v.y;
+    aq[4 * t + 2] = v.z;
+    aq[4 * t + 3] = v.w;
+  }
   for (uint32_t g0 = 0; g0 < ntiles; g0 += T) {
     f32x16 acc[T];
 #pragma unroll
@@ -757,27 +747,18 @@ __global__ void __launch_bounds__(256)
       acc[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (uint32_t c = 0; c < nch; ++c) {
-      // the query chunk of (g0, c) was loaded during the last tile of the previous (group, chunk)
-      // -- see below -- except for the very first one
-      if (g0 == 0 && c == 0) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float4 v = qw.piece(h * Dh, t);
-          aq[4 * t + 0] = v.x;
-          aq[4 * t + 1] = v.y;
-          aq[4 * t + 2] = v.z;
-          aq[4 * t + 3] = v.w;
-        }
-      }
       const uint32_t next_col = ((c + 1 < nch) ? (c + 1) * CW : 0u) + h * Dh;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const uint32_t tt = g0 + t;
-        if (tt >= ntiles)
-          break;  // uniform
+        // A group always runs its T tiles: one that lies past the end of the range stages
+        // clamped rows with the padding norm (nothing is inserted from it, the epilogue skips it).
+        // That makes "last tile of the chunk" a compile-time property (t == T - 1), so there is ONE
+        // prefetch site writing the operand registers -- two sites in different copies of the
+        // chain are a phi again (64 copies behind a wait for vmcnt(0) per iteration).
         // the pair after this one: next tile of the group, else next chunk, else next group
         bool has_next = true;
-        const bool last_of_chunk = !(t + 1 < T && tt + 1 < ntiles);
+        const bool last_of_chunk = t + 1 == T;
         uint32_t n_tile = tt + 1, n_chunk = c;
         if (last_of_chunk) {
           if (c + 1 < nch) {
@@ -800,16 +781,19 @@ __global__ void __launch_bounds__(256)
         // chunk as soon as its MFMAs have been issued: the loads travel while the rest of the
         // chain runs, instead of stalling the first MFMA of the next chunk.
         const float* bt = lds_f + (p & 1) * tile_floats + j * DP + h * Dh;
-        // two copies of the chain, the branch outside: each is ONE basic block, so the LDS reads
-        // of the B operand are scheduled ahead of the MFMAs that consume them
-        if (last_of_chunk)
+        // (each copy of the chain is ONE basic block, so the LDS reads of the B operand are
+        // scheduled ahead of the MFMAs that consume them)
+        if (t + 1 == T)  // constant after unrolling
           mfma_chain<NU, true>(acc[t], aq, bt, qw, next_col);
         else
           mfma_chain<NU, false>(acc[t], aq, bt, qw, next_col);
+        GGNN_BF_TICK(0);
         if (has_next)
           stage.store_shifted(lds_f + ((p + 1) & 1) * tile_floats, DP, CW, mean_lds,
                               n_chunk * CW);
+        GGNN_BF_TICK(2);
         __syncthreads();
+        GGNN_BF_TICK(3);
         ++p;
       }
     }
@@ -847,7 +831,15 @@ __global__ void __launch_bounds__(256)
         continue;
       bf_insert_hits(dd, thr2, row0, wave_d2, list_id + wave * 32 * KP, KP, h);
     }
+    GGNN_BF_TICK(1);
   }
+#ifdef GGNN_BF_PHASE
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i)
+      atomicAdd(&g_bf_phase[i], bf_ph[i]);
+    atomicAdd(&g_bf_phase[4], static_cast<unsigned long long>(p));
+  }
+#endif
   }  // T > 1
 
   // partial results of this base slice / segment
@@ -859,7 +851,7 @@ __global__ void __launch_bounds__(256)
       a.part_dists[o] = list_d[wave * 32 * KP + i];
     }
   }
-  } while (T == 1);
+  } while (a.equal_ranges);
 }
 
 // ---- 2b. uint8 rows, squared L2: the contraction on v_mfma_i32_32x32x32_i8 ------------------------
@@ -1129,7 +1121,7 @@ bool bf_mfma_supported(const BfLaunch& a)
   // tiles + candidate lists (+ the shift vector of the chunked kernel) must fit into 160 KB of LDS
   const size_t lists = 2ull * kBfQueriesPerBlock * (a.k_query + 8);
   const size_t tiles = 2ull * kBfTileRows * 132;
-  const size_t shift = a.D > 128 ? (a.D + 3) / 4 * 4 : 128 + 2 * kBfQueriesPerBlock;
+  const size_t shift = a.D > 128 ? (a.D + 127) / 128 * 128 : 128 + 2 * kBfQueriesPerBlock;
   return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
@@ -1176,16 +1168,19 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   uint32_t rows_per_slice = (a.N_base + slices - 1) / slices;
   rows_per_slice = (rows_per_slice + kBfTileRows - 1) / kBfTileRows * kBfTileRows;
   slices = (a.N_base + rows_per_slice - 1) / rows_per_slice;
-  // single-chunk float kernel: Nq/128 * N/32 (query block, tile) pairs in one sequence, cut into
+  // float tile kernels: Nq/128 * N/(32 T) (query block, unit) pairs in one sequence, cut into
   // `resident` equal ranges -- every workgroup slot of the chip gets the same work whatever Nq is
   // (79 query blocks x 9 slices left 7 % of the slots empty).  A query block then has up to
-  // ceil(tiles_per_q / range) + 1 parts; ranges are at least 1/32 of a query block (the lists of
-  // every part start empty, and what they accept before their thresholds settle is the cost).
-  // Hook BF_SLICES: ranges of 1/BF_SLICES of a query block, i.e. the aligned slices of old.
-  const uint32_t tiles_per_q = (a.N_base + kBfTileRows - 1) / kBfTileRows;
+  // ceil(units per query block / range) + 1 parts; ranges are at least 1/32 of a query block (the
+  // lists of every part start empty, and what they accept before their thresholds settle is the
+  // cost).  Hook BF_SLICES: ranges of 1/BF_SLICES of a query block.
+  const bool equal_ranges = !use_i8;
+  const uint32_t unit_tiles = a.D > 128 ? (hook(kHookBfTiles) == 4 ? 4u : 2u) : 1u;
+  const uint32_t unit_rows = unit_tiles * kBfTileRows;
+  const uint32_t tiles_per_q = (a.N_base + unit_rows - 1) / unit_rows;
   const uint64_t total_tiles = static_cast<uint64_t>(qblocks) * tiles_per_q;
   uint32_t tiles_per_block = 0, nblocks = 0;
-  if (single_chunk) {
+  if (equal_ranges) {
     uint64_t per = (total_tiles + resident - 1) / resident;
     per = std::max<uint64_t>(per, (tiles_per_q + 31) / 32);
     if (const int64_t hs = hook(kHookBfSlices); hs > 0)
@@ -1235,7 +1230,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   if (use_i8v2)  // +inf
     GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7f800000, a.Nq,
                                      stream));
-  if (single_chunk) {
+  if (equal_ranges) {
     // not every query block has all `slices` parts: the others read as empty lists
     GGNN_HIP_CHECK(hipMemsetAsync(part_ids, 0xff, parts * sizeof(int32_t), stream));
     GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(part_dists), 0x7f800000,
@@ -1276,12 +1271,14 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   m.KP = KP;
   m.slices = slices;
   m.rows_per_slice = rows_per_slice;
+  m.equal_ranges = equal_ranges ? 1 : 0;
   m.tiles_per_q = tiles_per_q;
   m.tiles_per_block = tiles_per_block;
   m.total_tiles = total_tiles;
   // the shift vector sits in LDS (single chunk: its 2*Dh columns; 128 query norms and 128
   // thresholds follow)
-  m.DM = a.D > 128 ? (a.D + 3) / 4 * 4 : 2 * Dh;
+  // (zero past column D up to the end of the last chunk: see TileStage<float>::load)
+  m.DM = a.D > 128 ? (a.D + 127) / 128 * 128 : 2 * Dh;
   const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM +
                       (a.D > 128 ? 0 : 2 * kBfQueriesPerBlock)) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
@@ -1325,7 +1322,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
       GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                          static_cast<int>(lds)));                                 \
     void* kargs[] = {&m};                                                                         \
-    const dim3 grid = single_chunk ? dim3(nblocks) : dim3(qblocks, slices);                       \
+    const dim3 grid = equal_ranges ? dim3(nblocks) : dim3(qblocks, slices);                       \
     GGNN_HIP_CHECK(hipLaunchKernel(kern, grid, dim3(256), kargs, lds, stream));                   \
   } while (0)
   if (use_i8) {
@@ -1348,8 +1345,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     launch_bf_i8v2(m, qblocks, slices, warm, stream);
   }
   else if (use_i8) {
+    // (+ 128 words: bf_insert_hits reads up to 126 words past the last list unconditionally)
     const size_t lds8 = 2 * kBfI8Tiles * kBfTileRows * kBfI8RowStride +
-                        2 * kBfQueriesPerBlock * KP * sizeof(float);
+                        2 * kBfQueriesPerBlock * KP * sizeof(float) + 128 * sizeof(float);
     const uint32_t nm = (a.D + 31) / 32;
     const void* kern = nm == 1   ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<1>)
                        : nm == 2 ? reinterpret_cast<const void*>(&bf_mfma_i8_kernel<2>)

@@ -10,8 +10,9 @@ import torch
 from ggnn_amd import _lib, ops
 from bench import synthetic
 dev = torch.device("cuda", 0)
-base = synthetic("lowrank16", 1_000_000, 128, 1234, dev)
-q = synthetic("lowrank16", 10_000, 128, 4321, dev)
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 128   # > 128: the chunked kernel, per (tile, chunk) pair
+base = synthetic("lowrank16", 1_000_000, D, 1234, dev)
+q = synthetic("lowrank16", 10_000, D, 4321, dev)
 h = C.CDLL(_lib.LIB_PATH)
 for _ in range(2):
     ops.bf_query(base, q, 10)
@@ -26,7 +27,5 @@ tiles = acc[4]
 out = {n: round(acc[i] / tiles, 1) for i, n in enumerate(names)}
 out["total per wave-tile"] = round(sum(acc[i] for i in range(4)) / tiles, 1)
 out["wave-tiles"] = tiles
-out["tiles with a hit"] = round(acc[5] / tiles, 3)
-out["insertions per wave-tile"] = round(acc[6] / tiles, 3)
 out["bf_query ms (stats build)"] = round(e0.elapsed_time(e1), 2)
 print(json.dumps(out, indent=1))
