@@ -14,6 +14,7 @@ constexpr uint32_t kBfMaxKP = 120;  // lists of 128 queries must fit into LDS ne
 struct BfMfmaArgs {
   const void* base;
   const void* query;
+  const float* query_packed;  // chunked float kernel: operand-order copy (bf_mfma.hip QueryWindow)
   const float* mean;   // [D] shift applied to base and query rows (float32 squared L2), or null
   const float* bnorm;
   const float* qnorm;

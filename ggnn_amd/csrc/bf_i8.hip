@@ -362,8 +362,8 @@ __global__ void __launch_bounds__(256)
     const uint32_t row0 = begin + st * SR;
     const uint32_t buf = st & 1;
     const uint8_t* blk = lds_b + buf * stage_bytes;
-    // set `cur` held stage st (in LDS since the end of the previous stage): reuse it for st + 2
-    stage_load(row0 + 2 * SR, v_cur, bn_cur);
+    // (the exchange first: it waits for its own atomic load with vmcnt(0), which must not have
+    // this stage's freshly issued staging loads in front of it)
 #if !defined(GGNN_I8_EXP) || GGNN_I8_EXP != 2   // (2: timing experiment without the exchange)
     if (st && st % kI8v2Refresh == 0) {
       I8_T0();
@@ -371,6 +371,8 @@ __global__ void __launch_bounds__(256)
       I8_T1(12);
     }
 #endif
+    // set `cur` held stage st (in LDS since the end of the previous stage): reuse it for st + 2
+    stage_load(row0 + 2 * SR, v_cur, bn_cur);
     // the B operands of tile t + 1 are requested while the MFMAs of tile t run (the hit handling
     // in between touches LDS, so the compiler keeps the reads behind it on its own)
     i32x4 bq[2][NM];

@@ -227,6 +227,7 @@ struct TileStage<float> {
                                               min(col, D - 4));
     }
   }
+  GGNN_DEV float norm() const { return threadIdx.x < rows ? bn : bn_pad; }  // threads 0..31
   // the shift of columns [col0, col0 + CW) is read from the shift vector in LDS, which is zero
   // past column D (so that the clamped columns stay finite)
   GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float* mean_lds,
@@ -276,6 +277,7 @@ struct TileStage<uint8_t> {
     r = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(min(row0 + row, last)) * D +
                                         min(col, D - 16));
   }
+  GGNN_DEV float norm() const { return threadIdx.x < rows ? bn : bn_pad; }  // threads 0..31
   GGNN_DEV void store_shifted(float* tile, uint32_t DP, uint32_t CW, const float*, uint32_t) const
   {
     if (threadIdx.x < (uint32_t)kBfTileRows)
@@ -454,44 +456,69 @@ GGNN_DEV void bf_test_and_insert(const float (&dd)[16], float* thr_w, uint32_t r
   bf_insert_hits(dd, thr, row0, wave_d, wave_id, KP, h, thr_w);
 }
 
-// Query operands of the chunked kernel are fetched with BUFFER loads through a descriptor that
-// spans exactly this workgroup's query rows: out-of-range offsets return zero in hardware, so
-// padding queries (rows past Nq) and columns past D need neither a branch nor a select, the value
-// lands directly in the operand registers and nothing waits for it until the next chunk's MFMAs.
+// Query operands of the chunked kernel come from a PACKED copy of the query set
+// (pack_query_kernel): [query block][wave][chunk][piece t][lane] float4, i.e. the sixteen bytes lane
+// (j, h) needs for piece t of a chunk -- columns 128 c + 64 h + 4 t .. + 3 of query row j -- sit at
+// lane * 16 of a contiguous 1 KB block, so one load instruction of a wave is one contiguous
+// kilobyte.  (Read from the row-major query set, the same instruction touched 64 different 128-byte
+// lines for 16 bytes each -- eight times the bytes through the L1 / L2 path, and the operand
+// stream is twice the size of the base tiles to begin with.)  Padding queries and columns past D
+// are zero in the copy.  Buffer loads: the piece index goes into the scalar offset, the lane into
+// the vector offset, no address arithmetic per load.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <typename BaseT>
 struct QueryWindow {
   __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t row_bytes;   // byte offset of this lane's query row inside the window
-  uint32_t D;
-  GGNN_DEV void open(const BaseT* query, uint32_t Nq, uint32_t D_, uint32_t q0, uint32_t row)
+  uint32_t lane_bytes;
+  GGNN_DEV void open(const float* packed, uint32_t nch, uint32_t qblock, uint32_t wave,
+                     uint32_t lane)
   {
-    const uint32_t rows = Nq > q0 ? min(static_cast<uint32_t>(kBfQueriesPerBlock), Nq - q0) : 0u;
+    const uint32_t wave_bytes = nch * 16u * 64u * 16u;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<BaseT*>(query + static_cast<size_t>(q0) * D_), 0,
-        rows * D_ * static_cast<uint32_t>(sizeof(BaseT)), 0x00020000);
-    row_bytes = row * D_ * static_cast<uint32_t>(sizeof(BaseT));
-    D = D_;
+        const_cast<float*>(packed) + (static_cast<size_t>(qblock) * 4 + wave) * (wave_bytes / 4), 0,
+        wave_bytes, 0x00020000);
+    lane_bytes = lane * 16u;
   }
-  // four operands of piece t (columns col_h + 4t ...) of a chunk
+  // four operands of piece t of the chunk that starts at column col_h - 64 h (a multiple of 128)
   GGNN_DEV float4 piece(uint32_t col_h, int t) const
   {
-    const uint32_t col = col_h + 4 * t;
-    // past the row: an offset outside the window, which reads as zero
-    const uint32_t off = col < D ? row_bytes + col * static_cast<uint32_t>(sizeof(BaseT))
-                                 : 0xffffffffu;
-    if constexpr (std::is_same<BaseT, float>::value) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-      return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                         __uint_as_float(v.w));
-    }
-    else {
-      const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
-      return make_float4(static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu),
-                         static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24));
-    }
+    const uint32_t c = col_h >> 7;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes,
+                                                          (c * 16u + static_cast<uint32_t>(t)) * 1024u, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                       __uint_as_float(v.w));
   }
 };
+
+// the packed copy (see QueryWindow); `query` is what the tile kernel works on (the shifted copy
+// for float32 squared L2), out has query blocks * 4 * nch * 16 * 64 float4
+template <typename BaseT>
+__global__ void __launch_bounds__(256) pack_query_kernel(const BaseT* query, uint32_t Nq, uint32_t D,
+                                                        uint32_t nch, uint64_t n4, float4* out)
+{
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4;
+       i += static_cast<uint64_t>(gridDim.x) * 256) {
+    const uint32_t lane = static_cast<uint32_t>(i & 63);
+    uint64_t r = i >> 6;
+    const uint32_t t = static_cast<uint32_t>(r & 15);
+    r >>= 4;
+    const uint32_t c = static_cast<uint32_t>(r % nch);
+    r /= nch;
+    const uint32_t w = static_cast<uint32_t>(r & 3);
+    const uint64_t q = (r >> 2) * kBfQueriesPerBlock + w * 32 + (lane & 31);
+    const uint32_t col = c * 128 + (lane >> 5) * 64 + 4 * t;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Nq && col < D) {  // (D is a multiple of 4 / 16: all four columns exist)
+      if constexpr (std::is_same<BaseT, float>::value)
+        v = *reinterpret_cast<const float4*>(query + q * D + col);
+      else {
+        const uint32_t b = *reinterpret_cast<const uint32_t*>(query + q * D + col);
+        v = make_float4(static_cast<float>(b & 0xffu), static_cast<float>((b >> 8) & 0xffu),
+                        static_cast<float>((b >> 16) & 0xffu), static_cast<float>(b >> 24));
+      }
+    }
+    out[i] = v;
+  }
+}
 
 // 4*NU MFMA steps of one (tile, chunk) pair: acc += aq x B with B read from the LDS tile row bt.
 // PREFETCH: every group of four query operands is reloaded for the next chunk (columns from
@@ -499,9 +526,9 @@ struct QueryWindow {
 // software pipeline -- B operand of step u+1 from LDS, the four MFMAs of step u, the query piece u
 // of the next chunk -- so that the prefetched values reuse the operand registers they replace
 // (hoisting all sixteen loads needs 64 more registers: 55 spills at two waves per SIMD).
-template <int NU, bool PREFETCH, typename BaseT>
-GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt,
-                         const QueryWindow<BaseT>& qw, uint32_t next_col)
+template <int NU, bool PREFETCH>
+GGNN_DEV void mfma_chain(f32x16& acc, float (&aq)[64], const float* bt, const QueryWindow& qw,
+                         uint32_t next_col)
 {
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -579,6 +606,10 @@ __global__ void __launch_bounds__(256)
   float* mean_lds = reinterpret_cast<float*>(list_id + kBfQueriesPerBlock * a.KP);
   float* qn_lds = mean_lds + a.DM;
   float* thr_lds = qn_lds + kBfQueriesPerBlock;
+  // chunked kernel: row norms of the tiles of the current and the next group (the next group's
+  // first tile is staged before the current group's epilogue), [group parity][tile][row]; the
+  // epilogue reads them from here -- a global load there is a round trip of its own per group
+  float* bn_grp = thr_lds;  // (the single-chunk kernel keeps its thresholds in these words)
   for (uint32_t i = tid; i < a.DM; i += 256)
     mean_lds[i] = (a.mean && i < a.D) ? a.mean[i] : 0.f;
 
@@ -624,7 +655,7 @@ __global__ void __launch_bounds__(256)
   }
   const bool qvalid = qbase + j < a.Nq;
   const BaseT* qrow = query + static_cast<size_t>(qvalid ? qbase + j : 0) * a.D;
-  if constexpr (T == 1) {
+  {
     if (lane < 32) {  // this wave's entries only: nothing to order against the other waves
       const uint32_t qi = qbase + lane;
       qn_lds[wave * 32 + lane] = qi < a.Nq ? a.qnorm[qi] : 0.f;
@@ -642,6 +673,8 @@ __global__ void __launch_bounds__(256)
     if constexpr (T > 1) {
       stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
       stage.store_shifted(lds_f, DP, CW, mean_lds, 0);
+      if (tid < kBfTileRows)
+        bn_grp[tid] = stage.norm();
     }
     else {
       stage.load(base, a.D, begin, end, 0, CW, a.bnorm, bn_pad);
@@ -719,9 +752,9 @@ __global__ void __launch_bounds__(256)
 #endif
   }
   else {
-  // this workgroup's 128 query rows as a buffer window (rows past Nq are out of range: zero)
-  QueryWindow<BaseT> qw;
-  qw.open(query, a.Nq, a.D, qblock * kBfQueriesPerBlock, wave * 32 + j);
+  // this wave's block of the packed query copy (a.query_packed)
+  QueryWindow qw;
+  qw.open(a.query_packed, nch, qblock, wave, lane);
   uint32_t p = 0;  // (tile, chunk) pairs processed: buffer p&1 holds the current pair
 #ifdef GGNN_BF_PHASE
   unsigned long long bf_ph[5] = {0, 0, 0, 0, 0};
@@ -788,9 +821,12 @@ __global__ void __launch_bounds__(256)
         else
           mfma_chain<NU, false>(acc[t], aq, bt, qw, next_col);
         GGNN_BF_TICK(0);
-        if (has_next)
+        if (has_next) {
           stage.store_shifted(lds_f + ((p + 1) & 1) * tile_floats, DP, CW, mean_lds,
                               n_chunk * CW);
+          if (n_chunk == 0 && tid < kBfTileRows)
+            bn_grp[((((n_tile / T) & 1) * T) + n_tile % T) * kBfTileRows + tid] = stage.norm();
+        }
         GGNN_BF_TICK(2);
         __syncthreads();
         GGNN_BF_TICK(3);
@@ -801,15 +837,15 @@ __global__ void __launch_bounds__(256)
     // epilogue: distances of column j (base row row0+j) to the lane's 16 query rows.  The
     // thresholds (worst list entry of each of the lane's query rows) live in registers and change
     // only after an insertion, so the common case is 16 x (add, fma, compare) and one branch.
-    // (thresholds and query norms are fetched here, not held across the MFMA loop: 32 registers
-    // less, which is what lets a second workgroup share the CU)
+    // (thresholds and query norms are fetched here -- from LDS -- not held across the MFMA loop:
+    // 32 registers less, which is what lets a second workgroup share the CU)
     float* wave_d2 = list_d + wave * 32 * KP;
     float thr2[16], qn2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const uint32_t ql = (r & 3) + 8 * (r >> 2) + 4 * h;
       thr2[r] = wave_d2[ql * KP + KP - 1];   // -inf for padding queries (list initialisation)
-      qn2[r] = qbase + ql < a.Nq ? a.qnorm[qbase + ql] : 0.f;
+      qn2[r] = qn_lds[wave * 32 + ql];
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -819,7 +855,7 @@ __global__ void __launch_bounds__(256)
       const uint32_t row0 = begin + tt * kBfTileRows;
       const bool jvalid = row0 + j < end;
       // rows past the end: +inf norm -> +inf distance (L2); handled explicitly for cosine
-      const float bn = jvalid ? a.bnorm[row0 + j] : (MODE == kL2 ? inf_f() : 0.f);
+      const float bn = bn_grp[(((g0 / T) & 1) * T + t) * kBfTileRows + j];
       float dd[16];
       unsigned long long any = 0;
 #pragma unroll
@@ -1121,7 +1157,8 @@ bool bf_mfma_supported(const BfLaunch& a)
   // tiles + candidate lists (+ the shift vector of the chunked kernel) must fit into 160 KB of LDS
   const size_t lists = 2ull * kBfQueriesPerBlock * (a.k_query + 8);
   const size_t tiles = 2ull * kBfTileRows * 132;
-  const size_t shift = a.D > 128 ? (a.D + 127) / 128 * 128 : 128 + 2 * kBfQueriesPerBlock;
+  const size_t shift = a.D > 128 ? (a.D + 127) / 128 * 128 + 3 * kBfQueriesPerBlock
+                                 : 128 + 2 * kBfQueriesPerBlock;
   return (lists + tiles + shift) * sizeof(float) <= 160 * 1024;
 }
 
@@ -1211,8 +1248,11 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_rescan = pad4(rescan_entries);
   const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
   const size_t n_gthr = use_i8v2 ? pad4(a.Nq) : 0;  // per-query bound shared by the slices
-  const size_t words =
-      n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan + n_qshift + n_gthr;
+  // chunked float kernel: the query set once more, in operand order (QueryWindow)
+  const uint32_t pack_chunks = (!use_i8 && a.D > 128) ? (a.D + 127) / 128 : 0;
+  const size_t n_qpack = static_cast<size_t>(qblocks) * kBfQueriesPerBlock * pack_chunks * 128;
+  const size_t words = n_norms + n_mean + n_partial + 4 + n_list + 2 * n_parts + 2 * n_rescan +
+                       pad4(n_qshift) + n_gthr + n_qpack;
   float* scratch = static_cast<float*>(scratch_alloc(words * 4, stream));
   float* bnorm = scratch;
   float* qnorm = bnorm + a.N_base;
@@ -1225,7 +1265,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   int32_t* rescan_ids = reinterpret_cast<int32_t*>(part_dists + n_parts);
   float* rescan_dists = reinterpret_cast<float*>(rescan_ids + n_rescan);
   float* q_shifted = rescan_dists + n_rescan;
-  uint32_t* gthr = reinterpret_cast<uint32_t*>(q_shifted + n_qshift);
+  uint32_t* gthr = reinterpret_cast<uint32_t*>(q_shifted + pad4(n_qshift));
+  float* q_packed = reinterpret_cast<float*>(gthr + n_gthr);
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
   if (use_i8v2)  // +inf
     GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7f800000, a.Nq,
@@ -1255,9 +1296,23 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   // what the tile and norm kernels see as the query set (the re-rank works on the original rows)
   const void* tile_query = center ? static_cast<const void*>(q_shifted) : a.query;
 
+  if (pack_chunks) {
+    const uint64_t n4 = n_qpack / 4;
+    const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((n4 + 255) / 256, 8192)));
+    if (a.dtype == GGNN_F32)
+      hipLaunchKernelGGL((pack_query_kernel<float>), grid, dim3(256), 0, stream,
+                         static_cast<const float*>(tile_query), a.Nq, a.D, pack_chunks, n4,
+                         reinterpret_cast<float4*>(q_packed));
+    else
+      hipLaunchKernelGGL((pack_query_kernel<uint8_t>), grid, dim3(256), 0, stream,
+                         static_cast<const uint8_t*>(tile_query), a.Nq, a.D, pack_chunks, n4,
+                         reinterpret_cast<float4*>(q_packed));
+  }
+
   BfMfmaArgs m{};
   m.base = a.base;
   m.query = tile_query;
+  m.query_packed = q_packed;
   m.mean = d_mean;
   m.bnorm = bnorm;
   m.qnorm = qnorm;
@@ -1275,12 +1330,13 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   m.tiles_per_q = tiles_per_q;
   m.tiles_per_block = tiles_per_block;
   m.total_tiles = total_tiles;
-  // the shift vector sits in LDS (single chunk: its 2*Dh columns; 128 query norms and 128
-  // thresholds follow)
+  // the shift vector sits in LDS (single chunk: its 2*Dh columns); 128 query norms and 128
+  // thresholds (single chunk only) follow
   // (zero past column D up to the end of the last chunk: see TileStage<float>::load)
   m.DM = a.D > 128 ? (a.D + 127) / 128 * 128 : 2 * Dh;
+  // (chunked kernel: [2][T <= 4][32] row norms in place of the thresholds)
   const size_t lds = (2 * kBfTileRows * DP + 2 * kBfQueriesPerBlock * KP + m.DM +
-                      (a.D > 128 ? 0 : 2 * kBfQueriesPerBlock)) * sizeof(float);
+                      (a.D > 128 ? 3 : 2) * kBfQueriesPerBlock) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
   // rows longer than one chunk: base tiles per accumulator group (hook BF_TILES = 2 | 4)
   const int tiles_per_group = hook(kHookBfTiles) == 4 ? 4 : 2;
