@@ -574,7 +574,7 @@ GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
 // ahead of the MFMAs that consume them.
 template <typename BaseT, int MODE, int T, int NU>
 __global__ void __launch_bounds__(256)
-    __attribute__((amdgpu_waves_per_eu(T == 2 ? 2 : T == 1 ? 3 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
+    __attribute__((amdgpu_waves_per_eu(T == 1 ? 3 : T <= 3 ? 2 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   // the two tile buffers are addressed as lds_f + offset (never through a pointer array: a select
@@ -1212,7 +1212,9 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   // lists of every part start empty, and what they accept before their thresholds settle is the
   // cost).  Hook BF_SLICES: ranges of 1/BF_SLICES of a query block.
   const bool equal_ranges = !use_i8;
-  const uint32_t unit_tiles = a.D > 128 ? (hook(kHookBfTiles) == 4 ? 4u : 2u) : 1u;
+  const int64_t tiles_hook = hook(kHookBfTiles);
+  const uint32_t unit_tiles =
+      a.D > 128 ? (tiles_hook == 4 ? 4u : tiles_hook == 2 ? 2u : 3u) : 1u;
   const uint32_t unit_rows = unit_tiles * kBfTileRows;
   const uint32_t tiles_per_q = (a.N_base + unit_rows - 1) / unit_rows;
   const uint64_t total_tiles = static_cast<uint64_t>(qblocks) * tiles_per_q;
@@ -1339,7 +1341,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                       (a.D > 128 ? 3 : 2) * kBfQueriesPerBlock) * sizeof(float);
   GGNN_REQUIRE(lds <= 160 * 1024, GGNN_UNSUPPORTED, "k too large for the MFMA brute-force path");
   // rows longer than one chunk: base tiles per accumulator group (hook BF_TILES = 2 | 4)
-  const int tiles_per_group = hook(kHookBfTiles) == 4 ? 4 : 2;
+  const int tiles_per_group = static_cast<int>(unit_tiles);
 
   BfRerankArgs rr{};
   rr.base = a.base;
@@ -1370,6 +1372,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                        static_cast<const float*>(nullptr), qnorm, static_cast<uint32_t*>(nullptr)); \
     const void* kern = (a.D > 128) ? (tiles_per_group == 2                                             \
                            ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 2, 16>)      \
+                           : tiles_per_group == 3                                                 \
+                           ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 3, 16>)      \
                            : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>))     \
                        : (Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8>)  \
                        : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12>) \

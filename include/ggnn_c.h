@@ -240,7 +240,7 @@ void ggnn_set_log_level(int level);
  *   BF_I8_V1            0     1 = LDS-list i8 kernel instead of the register-set one
  *   BF_SLICES           0     0 auto | base slices per query block (1..64)
  *   BF_NO_CENTER        0     1 = float32 rows not shifted by the column mean (exercises the re-scan)
- *   BF_TILES            2     2 | 4 base tiles per accumulator group (D > 128)
+ *   BF_TILES            3     2 | 3 | 4 base tiles per accumulator group (D > 128)
  *   BF_I8_NOSHARE       0     1 = slices of the i8 kernel do not share their bound
  *   BF_I8_WARM          0     rows of a seeding launch of the i8 kernel (0 = none)
  *   BF_SCAN             0     1 = scan kernels instead of the matrix-core brute force
