@@ -7,8 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GGNN_AMD_LIB: another build of the same library (A/B measurements of kernel variants)
-LIB_PATH = os.environ.get("GGNN_AMD_LIB") or os.path.join(_HERE, "csrc", "libggnn_amd.so")
+LIB_PATH = os.path.join(_HERE, "csrc", "libggnn_amd.so")
+# GGNN_AMD_LIB names another build of the same library (A/B measurements of kernel variants).  Like
+# every other switch it is honoured only while GGNN_TEST_HOOKS=1 is set: a production process that
+# merely inherits the variable always loads the in-tree library.
+if os.environ.get("GGNN_TEST_HOOKS") == "1" and os.environ.get("GGNN_AMD_LIB"):
+    LIB_PATH = os.environ["GGNN_AMD_LIB"]
 
 OK, INVALID_ARGUMENT, INVALID_STATE, OUT_OF_RANGE, OUT_OF_MEMORY, DEVICE_ERROR, UNSUPPORTED, \
     IO_ERROR = range(8)

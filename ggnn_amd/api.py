@@ -196,6 +196,7 @@ class GGNN:
         self._shards = 1
         self._inflight = {}   # slot -> QueryTickets whose kernels may still be running
         self._num_gpus = 1
+        self._collect_counters = False
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -416,6 +417,7 @@ class GGNN:
 
     def set_collect_counters(self, enable=True):
         self._check(lib().ggnn_set_collect_counters(self._h, int(bool(enable))))
+        self._collect_counters = bool(enable)
 
     def last_query_parts(self):
         """half-batches the last blocking multi-GPU query() was searched in (2: the second half's

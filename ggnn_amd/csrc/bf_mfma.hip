@@ -659,12 +659,19 @@ __global__ void __launch_bounds__(256)
     if (lane < 32) {  // this wave's entries only: nothing to order against the other waves
       const uint32_t qi = qbase + lane;
       qn_lds[wave * 32 + lane] = qi < a.Nq ? a.qnorm[qi] : 0.f;
-      float t0v = qi < a.Nq ? inf_f() : -inf_f();
+      // Thresholds in LDS exist in the single-chunk kernel only.  In the chunked kernel these words
+      // are bn_grp (row norms every wave reads in its epilogue), and a wave that enters the next
+      // segment of its range early would overwrite them under a slower wave still in the previous
+      // segment's epilogue -- no barrier lies between the two (the chunked kernel takes its
+      // thresholds from the lists).
+      if constexpr (T == 1) {
+        float t0v = qi < a.Nq ? inf_f() : -inf_f();
 #ifdef GGNN_BF_PHASE
-      if (g_bf_dbg_bound && qi < a.Nq)
-        t0v = g_bf_dbg_bound[qi];
+        if (g_bf_dbg_bound && qi < a.Nq)
+          t0v = g_bf_dbg_bound[qi];
 #endif
-      thr_lds[wave * 32 + lane] = t0v;
+        thr_lds[wave * 32 + lane] = t0v;
+      }
     }
   }
   __syncthreads();

@@ -112,17 +112,40 @@ class ShardedGGNN:
         t = _as_tensor(query, what="query")
         nq = int(t.shape[0])
         split = self.split_blocking if self.split_blocking is not None else nq >= 4096
-        if split and nq >= 2 and hasattr(self.engine, "query_async"):
+        if split and nq >= 2 and self._can_split(t):
             h = nq // 2
-            first = self.query_async(t[:h], k_query, tau_query, max_iterations, measure, slot=0)
-            second = self.query_async(t[h:], k_query, tau_query, max_iterations, measure, slot=1)
-            a = self.finish(first)
-            b = self.finish(second)
-            self.last_query_parts = 2
-            return torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+            first = None
+            try:
+                first = self.query_async(t[:h], k_query, tau_query, max_iterations, measure, slot=0)
+            except RuntimeError:
+                # the asynchronous lanes are stricter than the blocking call (an engine whose
+                # shards take turns on the GPU refuses them, GGNN_UNSUPPORTED): every rank sees the
+                # same refusal before any collective was entered, so all fall back together
+                first = None
+            if first is not None:
+                second = self.query_async(t[h:], k_query, tau_query, max_iterations, measure, slot=1)
+                a = self.finish(first)
+                b = self.finish(second)
+                self.last_query_parts = 2
+                return torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
         self.last_query_parts = 1
         ids, dists = self.engine.query(t, k_query, tau_query, max_iterations, measure)
         return self._exchange(ids, dists, int(k_query))
+
+    def _can_split(self, t):
+        """the preconditions of the engine's asynchronous lanes, as the C-level split checks them
+        (engine.cpp query_split): the query on the GPU, rows that need no padding (16-byte
+        multiples), work counters off (they belong to one blocking launch) -- anything else keeps
+        the single blocking engine.query(), which accepts all of it"""
+        if not hasattr(self.engine, "query_async"):
+            return False
+        if not isinstance(self.engine, GGNN):
+            return True   # a stand-in engine (CPU tests) states its own limits by raising
+        if not t.is_cuda or (t.shape[1] * t.element_size()) % 16 or not t.is_contiguous():
+            return False
+        if getattr(self.engine, "_collect_counters", False):
+            return False
+        return True
 
     def bf_query(self, query, k_gt=100, measure=DistanceMeasure.Euclidean):
         ids, dists = self.engine.bf_query(query, k_gt, measure)

@@ -1,6 +1,6 @@
 """event counts of bf_i8v2_kernel (debug build with -DGGNN_I8_STATS):
     make -C ggnn_amd/csrc TARGET=libggnn_dbg.so OBJDIR=build_dbg EXTRA=-DGGNN_I8_STATS
-    GGNN_AMD_LIB=ggnn_amd/csrc/libggnn_dbg.so python scripts/bf_i8_stats.py"""
+    GGNN_TEST_HOOKS=1 GGNN_AMD_LIB=ggnn_amd/csrc/libggnn_dbg.so python scripts/bf_i8_stats.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

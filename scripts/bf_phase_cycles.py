@@ -1,6 +1,6 @@
 """Shader cycles per phase of a tile of the single-chunk f32 bf kernel (stats build):
     make -C ggnn_amd/csrc OBJDIR=build_bfph TARGET=libggnn_bfph.so EXTRA=-DGGNN_BF_PHASE
-    GGNN_AMD_LIB=$PWD/ggnn_amd/csrc/libggnn_bfph.so python scripts/bf_phase_cycles.py
+    GGNN_TEST_HOOKS=1 GGNN_AMD_LIB=$PWD/ggnn_amd/csrc/libggnn_bfph.so python scripts/bf_phase_cycles.py
 Per wave and tile: MFMA chain + test of the previous tile | insertions | stage store (waits for the
 prefetched rows) | barrier.  A tile's 64 v_mfma_f32_32x32x2_f32 occupy the matrix pipe for 4096
 cycles; two waves share a SIMD."""

@@ -1,6 +1,6 @@
 """Shader cycles per phase of a pop of the headline query kernel (stats build):
     make -C ggnn_amd/csrc OBJDIR=build_ph TARGET=libggnn_ph.so EXTRA=-DGGNN_PHASE_CYCLES   (query.o only)
-    GGNN_AMD_LIB=$PWD/ggnn_amd/csrc/libggnn_ph.so python scripts/phase_cycles.py
+    GGNN_TEST_HOOKS=1 GGNN_AMD_LIB=$PWD/ggnn_amd/csrc/libggnn_ph.so python scripts/phase_cycles.py
 Reports, for batches of 1024 (one wave per SIMD: a lone wave's latency chain) and 10 000 queries,
 the average cycles per pop spent in each phase (every phase boundary drains the memory counters)."""
 import ctypes as C, os, sys, json

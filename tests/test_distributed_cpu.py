@@ -100,6 +100,18 @@ def _worker(rank, world, port, tmp):
         assert torch.equal(ids2, ids) and torch.equal(d2, d)
         ids3, d3 = sg.query(query[:7], K, 0.6, 200)       # odd count: halves of 3 and 4
         assert torch.equal(ids3, ids[:7]) and torch.equal(d3, d[:7])
+        # an engine whose asynchronous lanes refuse the batch (the real one does for shards that
+        # take turns on the GPU: GGNN_UNSUPPORTED): the split falls back to ONE blocking search +
+        # one exchange on every rank, same result (round-4 advisor finding)
+        real_async = sg.engine.query_async
+
+        def refusing(*a, **kw):
+            raise RuntimeError("query_async: not available while shards are swapped")
+        sg.engine.query_async = refusing
+        ids4, d4 = sg.query(query, K, 0.6, 200)
+        assert sg.last_query_parts == 1
+        assert torch.equal(ids4, ids) and torch.equal(d4, d)
+        sg.engine.query_async = real_async
         sg.split_blocking = None
         with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
             f.write("ok")

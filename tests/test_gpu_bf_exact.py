@@ -226,6 +226,40 @@ def test_bf_mfma_equal_tile_ranges(ops, N, Nq, D, slices):
     assert torch.equal(ids[t], s_ids) and torch.equal(dists[t], s_d)
 
 
+@pytest.mark.parametrize("tiles", [2, 3, 4])
+@pytest.mark.parametrize("N,Nq,D", [
+    (300, 100_000, 160),   # 782 query blocks of 2-5 units each: every workgroup runs several segments
+    (1000, 60_000, 200),   # ranges a bit longer than one query block
+    (2100, 40_000, 132),   # a range = a fraction of a query block, not a multiple of its units
+])
+def test_bf_mfma_chunked_many_segments_per_workgroup(ops, N, Nq, D, tiles):
+    """Chunked kernel (D > 128, T = 2 / 3 / 4 tiles per accumulator group) with ranges that cross
+    many query-block boundaries: a workgroup runs several segments in one do/while, and a wave that
+    starts the next segment early must not disturb what a slower wave of the same workgroup still
+    reads in the previous segment's epilogue (the row norms `bn_grp`; round-4 advisor finding: the
+    next segment's threshold initialisation aliased them).  Fractional data, K = 10: every query
+    against the scan kernel would be slow, a strided sample + the block borders are compared."""
+    from ggnn_amd import _lib
+    rng = np.random.default_rng(77)
+    base = rng.normal(size=(N, D)).astype(np.float32)
+    q = rng.normal(size=(Nq, D)).astype(np.float32)
+    b, qq = dev(base), dev(q)
+    with _lib.hooks(BF_TILES=tiles):
+        for rep in range(3):   # timing-dependent: a few launches
+            ids, dists = ops.bf_query(b, qq, 10, 0)
+            if rep == 0:
+                ids0, dists0 = ids.clone(), dists.clone()
+            else:
+                assert torch.equal(ids, ids0) and torch.equal(dists, dists0)
+    sel = np.unique(np.concatenate([np.arange(0, Nq, max(1, Nq // 1500)), np.arange(Nq - 130, Nq),
+                                    np.arange(120, 140), np.arange(128 * 37 - 5, 128 * 37 + 5)]))
+    sub = dev(q[sel])
+    parts = [ops.bf_query(b, sub[i:i + 200].contiguous(), 10, 0) for i in range(0, len(sel), 200)]
+    t = torch.from_numpy(sel).cuda()
+    assert torch.equal(ids[t], torch.cat([p[0] for p in parts]))
+    assert torch.equal(dists[t], torch.cat([p[1] for p in parts]))
+
+
 @pytest.mark.parametrize("N,D,Nq,K", [(50_000, 128, 700, 10), (33_333, 128, 257, 3), (20_001, 96, 300, 16),
                                       (9_000, 64, 513, 10), (4_100, 32, 256, 4), (70_000, 128, 1000, 1)])
 def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
