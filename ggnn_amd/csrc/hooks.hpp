@@ -30,6 +30,9 @@ enum Hook {
   kHookBfScan,          // BF_SCAN          1 = scan kernels instead of the matrix-core path
   kHookRcclFailAfter,   // RCCL_FAIL_AFTER  fault injection: the n-th exchange (1-based) reports an
                         //                  RCCL failure (0 = never); exercises the peer-copy fallback
+  kHookQueryEarly,      // QUERY_EARLY      0 = the query kernel's round-1..4 order (rows requested after
+                        //                  the membership test); 1 = early rows where the layout allows
+  kHookMergeEarly,      // MERGE_EARLY      the same switch for the merge kernel
   kHookCount
 };
 

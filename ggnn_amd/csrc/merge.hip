@@ -41,9 +41,16 @@ uint32_t merge_sorted_size(uint32_t KBuild)
   return std::max(64u, next_multiple32(KBuild + 1 + 16));
 }
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
+#ifndef GGNN_MERGE_WAVES_EARLY
+#define GGNN_MERGE_WAVES_EARLY 6   // see GGNN_QUERY_WAVES_EARLY (query.hip)
+#endif
+
+// EARLY (R = 1, KBuild <= 24): the pop order of traversal.hpp "Early rows", as in the query kernel
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0, bool EARLY = false>
 __global__ void __launch_bounds__(kWave)
-    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? GGNN_MERGE_WAVES : 1)))
+    __attribute__((amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? ((EARLY && PSC::enabled) ? GGNN_MERGE_WAVES_EARLY
+                                                                                       : GGNN_MERGE_WAVES)
+                                                            : 1)))
     merge_kernel(const MergeArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -62,8 +69,11 @@ __global__ void __launch_bounds__(kWave)
 
   const int m = (!a.layer_btm) ? n : a.translation_all[a.STs_off[a.layer_btm] + un];
 
-  DistEngine<BaseT, LPR, NCH> de;
-  de.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D);
+  // (early rows + pre-screen: the point's float row waits in LDS, see query.hip)
+  using DE = DistEngine<BaseT, LPR, NCH, EARLY && PSC::enabled>;
+  DE de;
+  de.template load_query<MODE>(base, a.D, base + static_cast<size_t>(static_cast<uint32_t>(m)) * a.D,
+                               lds_raw + wave_lds_ints(kMergeCache, HB));
   // exact pre-screen (traversal.hpp): the point is coded like any query, which reproduces its
   // stored codes and gives its own coding error
   PSC ps;
@@ -111,6 +121,39 @@ __global__ void __launch_bounds__(kWave)
     int spec_key = kEmptyKey, spec_row = kEmptyKey;
     const int32_t* layer_graph = a.graph_all + static_cast<size_t>(a.Ns_off[layer]) * K;
     for (uint32_t ite = 0; ite < kMergeIterations; ++ite) {
+      if constexpr (EARLY) {
+        const int anchor = sl.peek(sl.criteria());
+        if (anchor == kEmptyKey)
+          break;
+        ++cnt_pop;
+        const bool in_row = lane < static_cast<int>(K);  // K <= 24 (host)
+        int cand;
+        if (anchor == spec_key)
+          cand = spec_row;
+        else
+          cand = in_row ? layer_graph[static_cast<size_t>(static_cast<uint32_t>(anchor)) * K + lane]
+                        : kEmptyKey;
+        auto prefetch_head_row = [&]() {
+          spec_key = sl.key_at(sl.BEST);
+          if (spec_key != kEmptyKey)
+            spec_row = in_row ? layer_graph[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
+                                                K + lane]
+                              : kEmptyKey;
+        };
+        if constexpr (PSC::enabled) {
+          EarlyRows<PSC> er;
+          er.issue(ps, cand, tr);
+          sl.pop_commit(anchor, lds.known);
+          cnt_dist += fetch_early<MODE>(sl, de, lds, cand, er, ps, rows_read, prefetch_head_row, tr);
+        }
+        else {
+          EarlyRows<DE> er;
+          er.issue(de, cand, tr);
+          sl.pop_commit(anchor, lds.known);
+          cnt_dist += fetch_early<MODE>(sl, de, lds, cand, er, ps, rows_read, prefetch_head_row, tr);
+        }
+        continue;
+      }
       const int anchor = sl.pop(sl.criteria(), lds.known);
       if (anchor == kEmptyKey)
         break;
@@ -186,6 +229,18 @@ static void launch_merge_r(const MergeArgs& args, hipStream_t stream)
   const size_t lds = wave_lds_bytes(kMergeCache);
   // visited ring of 192 entries mirrored in a hash set (traversal.hpp) where the registers allow
   // it at 7 waves per SIMD (see launch_query_r)
+  constexpr bool early_layout = PSC::enabled ? (PsLayout<PSC>::lpr == 8 && PsLayout<PSC>::nch == 1)
+                                             : (LPR == 8 && NCH == 1);
+  if constexpr (early_layout) {
+    // hook MERGE_EARLY = 0: the round-1..4 order (A/B and test hook)
+    if (args.sorted <= 64 && args.KBuild <= 8 * kEarlySteps && hook(kHookMergeEarly) != 0) {
+      constexpr size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes;
+      hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1, true>),
+                         grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
+                         wave_lds_bytes(kMergeCache, 1) + qrow, stream, args);
+      return;
+    }
+  }
   if (args.sorted <= 64 && (PSC::enabled || NCH == 1))
     hipLaunchKernelGGL((merge_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1>), grid_for(xcd_grid_blocks(args.N_btm, args.xcd_map != 0)), dim3(kWave),
                        wave_lds_bytes(kMergeCache, 1), stream, args);

@@ -19,10 +19,19 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 #ifndef GGNN_QUERY_WAVES
 #define GGNN_QUERY_WAVES 7
 #endif
+// early rows + pre-screen: the requested code rows (15 registers) are live across the pop's
+// bookkeeping and the membership test; 72 registers spill 4-11 of them, 80 (6 waves) none
+#ifndef GGNN_QUERY_WAVES_EARLY
+#define GGNN_QUERY_WAVES_EARLY 6
+#endif
 
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0>
+// EARLY (R = 1, KBuild <= 24; traversal.hpp "Early rows"): the first-read rows of a pop's neighbours
+// are requested before the pop's bookkeeping and the membership test instead of after them.
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0, bool EARLY = false>
 __global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? GGNN_QUERY_WAVES : 1)))
+    amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? ((EARLY && PSC::enabled) ? GGNN_QUERY_WAVES_EARLY
+                                                                        : GGNN_QUERY_WAVES)
+                                             : 1)))
 query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
@@ -40,8 +49,12 @@ query_kernel(const QueryArgs a)
   const float nn1 = a.nn1_stats[1];
   const float xi = (MODE == kL2) ? (nn1 * nn1) * a.tau * a.tau : nn1 * a.tau;
 
-  DistEngine<BaseT, LPR, NCH> de;
-  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D);
+  // early rows + pre-screen: the float query row waits in LDS behind the wave's other regions (its
+  // registers are needed while the requested code rows are live across the membership test)
+  using DE = DistEngine<BaseT, LPR, NCH, EARLY && PSC::enabled>;
+  DE de;
+  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D,
+                               lds_raw + wave_lds_ints(is_tag_set(HB) ? a.sorted : a.cache, HB));
   PSC ps;
   load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
@@ -75,6 +88,41 @@ query_kernel(const QueryArgs a)
     // query_layer.cu:58-63
     const float d0 = sl.dist_at(0);
     sl.xi = (MODE == kL2) ? fminf(xi, d0 * a.tau * a.tau) : fminf(xi, d0 * a.tau);
+    if constexpr (EARLY) {
+      // the same pop, reordered: decide -> graph row (speculated, else loaded now) -> request the
+      // neighbours' first-read rows -> bookkeeping of the pop and membership test under that latency
+      const int anchor = sl.peek(sl.criteria());
+      if (anchor == kEmptyKey)
+        break;
+      ++cnt_pop;
+      const bool in_row = lane < static_cast<int>(a.KBuild);  // KBuild <= 24 (host)
+      int cand;
+      if (anchor == spec_key)
+        cand = spec_row;
+      else
+        cand = in_row ? a.graph0[static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild + lane]
+                      : kEmptyKey;
+      auto prefetch_head_row = [&]() {
+        spec_key = sl.key_at(sl.BEST);
+        if (spec_key != kEmptyKey)
+          spec_row = in_row ? a.graph0[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
+                                           a.KBuild + lane]
+                            : kEmptyKey;
+      };
+      if constexpr (PSC::enabled) {
+        EarlyRows<PSC> er;
+        er.issue(ps, cand);
+        sl.pop_commit(anchor, lds.known);
+        cnt_dist += fetch_early<MODE>(sl, de, lds, cand, er, ps, cnt_rows, prefetch_head_row);
+      }
+      else {
+        EarlyRows<DE> er;
+        er.issue(de, cand);
+        sl.pop_commit(anchor, lds.known);
+        cnt_dist += fetch_early<MODE>(sl, de, lds, cand, er, ps, cnt_rows, prefetch_head_row);
+      }
+      continue;
+    }
     const int anchor = sl.pop(sl.criteria(), lds.known);
     GGNN_TICK(0);  // pop
     if (anchor == kEmptyKey)
@@ -205,6 +253,14 @@ void query_sizing(uint32_t D, uint32_t k_query, uint32_t max_iterations, uint32_
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_lds(const QueryArgs& args, uint32_t sorted, hipStream_t stream);
 
+// layouts whose first row read is 8 lanes x one 16-byte chunk: Prescreen<8,1> next to any float
+// layout, or rows of <= 128 bytes read directly
+template <int LPR, int NCH, class PSC>
+constexpr bool early_rows_layout()
+{
+  return PSC::enabled ? (PsLayout<PSC>::lpr == 8 && PsLayout<PSC>::nch == 1) : (LPR == 8 && NCH == 1);
+}
+
 template <typename BaseT, int LPR, int NCH, int MODE, class PSC>
 static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t stream)
 {
@@ -215,6 +271,26 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   // no register for it at 7 waves per SIMD -- measured 2.73 vs 2.54 ms with the spills)
   const bool fits = PSC::enabled || NCH == 1;
   const uint32_t hb = (sorted <= 64 && fits) ? vis_hash_regs(args.cache - sorted) : 0;
+  // early rows (traversal.hpp): graph rows of <= 24 neighbours, first row read 8 lanes x 16 bytes
+  // (hook QUERY_EARLY = 0: the round-1..4 order, A/B and test hook)
+  if constexpr (early_rows_layout<LPR, NCH, PSC>()) {
+    // (not with the tag set of long rings: its state next to the requested rows spills 4-16
+    // registers, and a scratch reload waits for vmcnt(0), i.e. for the rows just requested)
+    const bool tagged = hb == 0 && fits && args.ring && (args.tag_bits == 8 || args.tag_bits == 9);
+    if (args.KBuild <= 8 * kEarlySteps && sorted <= 64 && !tagged && hook(kHookQueryEarly) != 0) {
+      constexpr size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes;
+      if (hb == 1)
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1, true>), grid_for(args.Nq),
+                           dim3(kWave), wave_lds_bytes(args.cache, 1) + qrow, stream, args);
+      else if (hb == 2)
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2, true>), grid_for(args.Nq),
+                           dim3(kWave), wave_lds_bytes(args.cache, 2) + qrow, stream, args);
+      else
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 0, true>), grid_for(args.Nq),
+                           dim3(kWave), lds + qrow, stream, args);
+      return;
+    }
+  }
   // long rings (searches of 1000-2000 iterations): tag set + ring in global memory (traversal.hpp)
   if (hb == 0 && sorted <= 64 && fits && args.ring && args.tag_bits == 8)
     hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -8>), grid_for(args.Nq),

@@ -173,10 +173,15 @@ struct WaveLds {
 };
 constexpr int kVisSlots = 8;    // keys per bucket of the hashed visited set
 constexpr int kVisStash = 32;   // overflow entries before the filter falls back to the ring scan
+// ints of one wave's regions (device and host); hash_regs < 0 (tag set) is sized separately
+__host__ __device__ inline size_t wave_lds_ints(uint32_t cache, int hash_regs = 0)
+{
+  const size_t hash_ints = hash_regs > 0 ? hash_regs * 64 * kVisSlots + kVisStash : 0;
+  return cache + WaveLds::extra_ints + hash_ints;
+}
 inline size_t wave_lds_bytes(uint32_t cache, uint32_t hash_regs = 0)
 {
-  const size_t hash_ints = hash_regs ? hash_regs * 64 * kVisSlots + kVisStash : 0;
-  return (cache + WaveLds::extra_ints + hash_ints) * sizeof(int);
+  return wave_lds_ints(cache, static_cast<int>(hash_regs)) * sizeof(int);
 }
 // bucket registers of the hashed visited set for a visited ring of `vis` entries: ~3 keys per
 // bucket on average when the ring is full; 0 = rings too long for it (see the tag set below)
@@ -580,10 +585,22 @@ struct SortedList {
   // simple_knn_cache.cuh:215-239 ; crit is criteria() (or criteria_sym() for the sym cache)
   GGNN_DEV int pop(float crit, int* known)
   {
+    const int k0 = peek(crit);
+    if (k0 != kEmptyKey)
+      pop_commit(k0, known);
+    return k0;
+  }
+  // the two halves of pop(): the decision (which key would be popped, simple_knn_cache.cuh:218-224)
+  // and the bookkeeping (:225-238).  Kernels that request the rows of the popped key's neighbours
+  // between the two hide the bookkeeping under that memory latency.
+  GGNN_DEV int peek(float crit) const
+  {
     const int k0 = key_at(BEST);
     const float d0 = dist_at(BEST);
-    if (k0 == kEmptyKey || d0 >= crit)
-      return kEmptyKey;
+    return (k0 == kEmptyKey || d0 >= crit) ? kEmptyKey : k0;
+  }
+  GGNN_DEV void pop_commit(const int k0, int* known)
+  {
     if constexpr (HB > 0) {
       if (!scan_mode) {
         if (vis_count == VIS)  // the ring wraps: its oldest key is forgotten
@@ -624,7 +641,6 @@ struct SortedList {
       }
     }
     head_in = (head_in + 1 >= P) ? 0 : head_in + 1;
-    return k0;
   }
 
   // simple_knn_cache.cuh:297-333 ; goes through LDS (known[0,SORTED)), called once per layer
@@ -661,6 +677,10 @@ struct SortedList {
 
   // filter part of fetch(): simple_knn_cache.cuh:246-261 / simple_knn_sym_cache.cuh:408-419.
   // cand: lanes j and j+32 hold candidate j (or EMPTY).  Returns cand with known keys blanked.
+  // AHEAD: the reads of the next pair of 16-byte groups are issued before the current pair is
+  // folded (a lone wave otherwise pays one LDS latency per pair).  The early-rows order runs the
+  // test under the latency of the candidates' row loads and prefers the 8 registers.
+  template <bool AHEAD = true>
   GGNN_DEV int filter(int cand, int* known) const
   {
     const int lane = threadIdx.x;
@@ -744,20 +764,32 @@ struct SortedList {
     const int T = (E + 7) >> 3;  // >= 4: SORTED >= 32
     // the reads of the next pair are issued before the current pair is folded: a lone wave
     // (small batches, tail of a launch) otherwise pays one LDS latency per pair
-    int4 e0 = p[0], e1 = p[2];
-    int t = 0;
-    for (; t + 4 <= T; t += 2) {
-      const int4 n0 = p[2 * t + 4], n1 = p[2 * t + 6];
+    if constexpr (AHEAD) {
+      int4 e0 = p[0], e1 = p[2];
+      int t = 0;
+      for (; t + 4 <= T; t += 2) {
+        const int4 n0 = p[2 * t + 4], n1 = p[2 * t + 6];
+        acc0 = fold(acc0, e0);
+        acc1 = fold(acc1, e1);
+        e0 = n0;
+        e1 = n1;
+      }
       acc0 = fold(acc0, e0);
       acc1 = fold(acc1, e1);
-      e0 = n0;
-      e1 = n1;
+      t += 2;
+      if (t < T)
+        acc0 = fold(acc0, p[2 * t]);
     }
-    acc0 = fold(acc0, e0);
-    acc1 = fold(acc1, e1);
-    t += 2;
-    if (t < T)
-      acc0 = fold(acc0, p[2 * t]);
+    else {
+      int t = 0;
+      for (; t + 2 <= T; t += 2) {
+        const int4 e0 = p[2 * t], e1 = p[2 * t + 2];
+        acc0 = fold(acc0, e0);
+        acc1 = fold(acc1, e1);
+      }
+      if (t < T)
+        acc0 = fold(acc0, p[2 * t]);
+    }
     return (min_over_halves(min(acc0, acc1)) == 0u) ? kEmptyKey : cand;
   }
 };
@@ -934,7 +966,11 @@ struct ChunkOf<uint8_t> {
 
 enum DistMode { kL2 = 0, kCos = 1 };
 
-template <typename BaseT, int LPR_, int NCH_>
+// QL: the query chunks live in LDS (q_lds[c * LPR + g], LPR * NCH chunks = one padded row per
+// wave) instead of NCH x 4 registers per lane, and are read where a distance is summed.  For
+// kernels whose register peak lies elsewhere (early rows: the requested code rows are live across
+// the membership test, the float rows are only needed for the ~4 candidates that pass).
+template <typename BaseT, int LPR_, int NCH_, bool QL = false>
 struct DistEngine {
   using Base = BaseT;
   using Chunk = typename ChunkOf<BaseT>::type;
@@ -942,14 +978,25 @@ struct DistEngine {
   static constexpr int LPR = LPR_;
   static constexpr int NCH = NCH_;
   static constexpr int ROWS = kWave / LPR;
+  static constexpr bool kQueryInLds = QL;
+  static constexpr size_t kQueryLdsBytes = QL ? sizeof(Chunk) * LPR_ * NCH_ : 0;
 
   const BaseT* base;
   uint32_t D;
   int g;  // lane within the row group
   bool all_chunks;  // wave-uniform: the row fills every chunk of every lane (e.g. D = 128 f32)
-  Chunk q[NCH];
+  Chunk q[QL ? 1 : NCH];
+  Chunk* q_lds;    // QL only
   float q_norm;    // cosine: |q|^2
   uint32_t qq_u8;  // uint8 rows: sum of squares of this lane's query elements
+
+  GGNN_DEV Chunk qchunk(int c) const
+  {
+    if constexpr (QL)
+      return q_lds[c * LPR + g];
+    else
+      return q[c];
+  }
 
   GGNN_DEV bool chunk_valid(int c) const
   {
@@ -965,38 +1012,43 @@ struct DistEngine {
   }
 
   // distance.cuh:104-117
+  // q_lds_: the wave's LPR * NCH chunks of LDS (QL only)
   template <int MODE>
-  GGNN_DEV void load_query(const BaseT* base_, uint32_t D_, const BaseT* qrow)
+  GGNN_DEV void load_query(const BaseT* base_, uint32_t D_, const BaseT* qrow, void* q_lds_ = nullptr)
   {
     base = base_;
     D = D_;
     g = threadIdx.x % LPR;
     all_chunks = D_ == static_cast<uint32_t>(LPR * NCH * EPC);
+    q_lds = static_cast<Chunk*>(q_lds_);
     float nrm = 0.f;
+    qq_u8 = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      q[c] = chunk_valid(c) ? load_chunk(qrow, c) : ChunkOf<BaseT>::zero();
+      const Chunk qc = chunk_valid(c) ? load_chunk(qrow, c) : ChunkOf<BaseT>::zero();
+      if constexpr (QL)
+        q_lds[c * LPR + g] = qc;  // (every row group writes the same values)
+      else
+        q[c] = qc;
       if (MODE == kCos) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          const float v = ChunkOf<BaseT>::get(q[c], e);
+          const float v = ChunkOf<BaseT>::get(qc, e);
           nrm = fmaf(v, v, nrm);
         }
+      }
+      if constexpr (std::is_same<BaseT, uint8_t>::value) {
+        qq_u8 = __builtin_amdgcn_udot4(qc.x, qc.x, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(qc.y, qc.y, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(qc.z, qc.z, qq_u8, false);
+        qq_u8 = __builtin_amdgcn_udot4(qc.w, qc.w, qq_u8, false);
       }
     }
     q_norm = 0.f;
     if (MODE == kCos)
       q_norm = group_sum<LPR>(nrm);
-    qq_u8 = 0;
-    if constexpr (std::is_same<BaseT, uint8_t>::value) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        qq_u8 = __builtin_amdgcn_udot4(q[c].x, q[c].x, qq_u8, false);
-        qq_u8 = __builtin_amdgcn_udot4(q[c].y, q[c].y, qq_u8, false);
-        qq_u8 = __builtin_amdgcn_udot4(q[c].z, q[c].z, qq_u8, false);
-        qq_u8 = __builtin_amdgcn_udot4(q[c].w, q[c].w, qq_u8, false);
-      }
-    }
+    if constexpr (QL)
+      __syncthreads();
   }
 
   // per-lane partial sums over the lane's chunks of one row
@@ -1009,10 +1061,11 @@ struct DistEngine {
       uint32_t ab = 0, bb = 0;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        ab = __builtin_amdgcn_udot4(v[c].x, q[c].x, ab, false);
-        ab = __builtin_amdgcn_udot4(v[c].y, q[c].y, ab, false);
-        ab = __builtin_amdgcn_udot4(v[c].z, q[c].z, ab, false);
-        ab = __builtin_amdgcn_udot4(v[c].w, q[c].w, ab, false);
+        const Chunk qc = qchunk(c);
+        ab = __builtin_amdgcn_udot4(v[c].x, qc.x, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].y, qc.y, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].z, qc.z, ab, false);
+        ab = __builtin_amdgcn_udot4(v[c].w, qc.w, ab, false);
         bb = __builtin_amdgcn_udot4(v[c].x, v[c].x, bb, false);
         bb = __builtin_amdgcn_udot4(v[c].y, v[c].y, bb, false);
         bb = __builtin_amdgcn_udot4(v[c].z, v[c].z, bb, false);
@@ -1032,10 +1085,11 @@ struct DistEngine {
     b = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+      const Chunk qc = qchunk(c);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const float o = ChunkOf<BaseT>::get(v[c], e);
-        const float qq = ChunkOf<BaseT>::get(q[c], e);
+        const float qq = ChunkOf<BaseT>::get(qc, e);
         if (MODE == kL2) {
           const float diff = o - qq;
           a = fmaf(diff, diff, a);
@@ -1152,6 +1206,7 @@ struct Prescreen {
   static constexpr int LPR = LPR_;
   static constexpr int NCH = NCH_;
   static constexpr int ROWS = kWave / LPR;
+  using Chunk = uint4;
 
   const uint8_t* codes;
   uint32_t Dc;  // code row length (multiple of 16)
@@ -1306,6 +1361,16 @@ struct PsFor<64, 16, MODE> {
   using type = Prescreen<64, 4, MODE>;
 };
 
+// lanes per row / chunks per lane of a pre-screen type (0 for NoPrescreen)
+template <class PS>
+struct PsLayout {
+  static constexpr int lpr = PS::LPR, nch = PS::NCH;
+};
+template <>
+struct PsLayout<NoPrescreen> {
+  static constexpr int lpr = 0, nch = 0;
+};
+
 // Drops the candidates of lds.ckeys[0,nsurv) whose lower bound reaches the criteria; the others
 // are compacted in place (order kept).  Returns their number.  translation: optional map from
 // candidate keys to base rows (upper graph layers).
@@ -1431,6 +1496,138 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
 {
   uint2 rows = make_uint2(0u, 0u);
   return fetch<MODE, FILTER>(sl, de, lds, cand, translation, NoPrescreen{}, rows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Early rows (round 5).  A pop of fetch() above is a chain of DEPENDENT steps: pop bookkeeping ->
+// graph row -> membership test -> compaction -> code rows (or the rows themselves) -> verdicts ->
+// float rows -> replay, i.e. every memory round trip starts only after the instruction chain in
+// front of it has run.  For graph rows of at most 24 neighbours (KBuild <= 24, every BASELINE
+// configuration) whose FIRST row read is 128 bytes wide -- 8 lanes x 16 bytes: the pre-screen codes
+// of a float base (Prescreen<8,1>) or the rows of a base with <= 128-byte rows (uint8 D <= 128,
+// DistEngine<.,8,1> without pre-screen) -- the order becomes
+//     decide the pop (peek) -> graph row (speculated: usually there) -> REQUEST the first-read
+//     rows of all <= 24 neighbours -> pop bookkeeping + membership test (under that latency) ->
+//     verdicts with the membership verdict applied as a mask -> [float rows -> distances] -> replay.
+// Candidate s*8 + grp goes to the eight lanes of group grp in step s (ds_bpermute), so there is no
+// compaction in front of the loads; known candidates are read too (21.4 of 24 survive the test
+// anyway) and are masked out afterwards.  Decisions, counters and results are those of fetch():
+// the set of evaluated candidates, their order and the criteria they meet are unchanged; only the
+// row counters (rows actually read) see the <= 24 requested rows instead of the survivors.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEarlySteps = 3;  // 24 candidates
+template <class RD>  // RD: the reader of the first rows (Prescreen<8,1,.> or DistEngine<.,8,1>)
+struct EarlyRows {
+  static_assert(RD::LPR == 8 && RD::NCH == 1, "early rows: 8 lanes x one 16-byte chunk per row");
+  int kk[kEarlySteps];                       // candidate key of this lane's row group, per step
+  typename RD::Chunk v[kEarlySteps][1];
+  // cand: lane j (< 24) holds candidate j or EMPTY; translation: optional map from candidate keys
+  // to base rows (upper graph layers of the merge kernel)
+  GGNN_DEV void issue(const RD& rd, const int cand, const int32_t* translation = nullptr)
+  {
+    const int grp = threadIdx.x >> 3;
+#pragma unroll
+    for (int s = 0; s < kEarlySteps; ++s) {
+      kk[s] = __builtin_amdgcn_ds_bpermute((s * 8 + grp) << 2, cand);
+      // EMPTY slots read row 0 (verdict ignored): no branch and no zero-fill around the loads
+      int m = max(kk[s], 0);
+      if (translation)
+        m = translation[m];
+      const auto* row = rd.row_ptr(m);
+      if (rd.all_chunks || rd.chunk_valid(0))
+        v[s][0] = rd.load_chunk(row, 0);
+      else
+        v[s][0] = typename RD::Chunk{};
+    }
+  }
+};
+
+// second half of a pop in the early-rows order: membership test, verdicts, exact phase, replay.
+// cand: lane j (< 24) holds candidate j or EMPTY (the value issue() was given).
+template <int MODE, class SL, class DE, class PS, class ER, class HOOK>
+GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, const ER& er,
+                         const PS& ps, uint2& rows, HOOK&& after_filter,
+                         const int32_t* translation = nullptr)
+{
+  const int lane = threadIdx.x;
+  const int grp = lane >> 3;
+  const bool g0 = (lane & 7) == 0;
+  const unsigned requested =
+      static_cast<unsigned>(__popcll(__ballot(lane < 8 * kEarlySteps && cand != kEmptyKey)));
+  cand = sl.template filter<false>(lower_half_to_both(cand), lds.known);
+  const unsigned surv = static_cast<unsigned>(__ballot(lane < 32 && cand != kEmptyKey));
+  const int nsurv = __popc(surv);
+  after_filter();
+  if constexpr (PS::enabled) {
+    rows.y += requested;
+    if (nsurv == 0)
+      return 0;
+    // +inf (list not full yet, pre-screen unusable): nothing is dropped, every survivor is evaluated
+    const float s_thr = ps.threshold(sl.criteria());
+    int neval = 0;
+#pragma unroll
+    for (int s = 0; s < kEarlySteps; ++s) {
+      const float S = group_sum<8>(ps.partial(er.v[s]));
+      const bool pass = ((surv >> (s * 8 + grp)) & 1u) && g0 && !(S >= s_thr);
+      const unsigned long long pm = __ballot(pass);
+      if (pass)
+        lds.ckeys[neval + __popcll(pm & ((1ull << lane) - 1ull))] = er.kk[s];
+      neval += __popcll(pm);
+    }
+    if (neval == 0)
+      return nsurv;
+    __syncthreads();
+    constexpr int kSteps = StepsOf<DE::LPR, DE::NCH>::value;
+    constexpr int kExactSteps = (DE::NCH == 3 && DE::ROWS >= 8) ? 1 : (kSteps > 2) ? 2 : kSteps;
+    compute_distances<MODE, DE, kExactSteps>(de, lds, neval, translation);
+    rows.x += neval;
+    __syncthreads();
+    const float cd = lane < neval ? lds.cd0[lane] : inf_f();
+    const int ck = lane < neval ? lds.ckeys[lane] : kEmptyKey;
+    // criteria() never increases during a fetch, so candidates failing it now fail it later
+    unsigned long long m = __ballot(cd < sl.criteria());
+    while (m) {
+      const int j = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const float d = rdlanef(cd, j);
+      const int k = rdlane(ck, j);
+      if (d < sl.criteria())
+        sl.push(k, d);
+    }
+    return nsurv;
+  }
+  else {
+    // the requested rows ARE the base rows: distances stay in the lanes that summed them (lane
+    // grp*8 of step s = candidate s*8 + grp), the replay reads them from there in candidate order
+    rows.x += requested;
+    if (nsurv == 0)
+      return 0;
+    float dd[kEarlySteps];
+#pragma unroll
+    for (int s = 0; s < kEarlySteps; ++s) {
+      float a, b;
+      de.template partial<MODE>(er.v[s], a, b);
+      a = group_sum<8>(a);
+      if (MODE == kCos)
+        b = group_sum<8>(b);
+      dd[s] = (MODE == kCos) ? de.finish_cos(a, b) : a;
+    }
+    const float crit = sl.criteria();
+#pragma unroll
+    for (int s = 0; s < kEarlySteps; ++s) {
+      unsigned long long m =
+          __ballot(((surv >> (s * 8 + grp)) & 1u) && g0 && dd[s] < crit);
+      while (m) {
+        const int j = __ffsll(static_cast<long long>(m)) - 1;
+        m &= m - 1;
+        const float d = rdlanef(dd[s], j);
+        const int k = rdlane(er.kk[s], j);
+        if (d < sl.criteria())
+          sl.push(k, d);
+      }
+    }
+    return nsurv;
+  }
 }
 
 // hook VIS_SLOTS = <1..8>: test hook that shrinks the buckets of the hashed visited set so that the

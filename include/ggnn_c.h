@@ -245,7 +245,12 @@ void ggnn_set_log_level(int level);
  *   BF_I8_WARM          0     rows of a seeding launch of the i8 kernel (0 = none)
  *   BF_SCAN             0     1 = scan kernels instead of the matrix-core brute force
  *   RCCL_FAIL_AFTER     0     fault injection: the n-th multi-GPU exchange of the process reports an
- *                             RCCL failure (exercises the peer-copy fallback); 0 = never */
+ *                             RCCL failure (exercises the peer-copy fallback); 0 = never
+ *   QUERY_EARLY         1     query kernel, graphs with KBuild <= 24: 1 = the first-read rows of a
+ *                             pop's neighbours (pre-screen codes, or rows of <= 128 bytes) are
+ *                             requested BEFORE the pop's bookkeeping and the membership test;
+ *                             0 = after them (the order of rounds 1-4; same results)
+ *   MERGE_EARLY         1     the same switch for the merge kernel */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);
