@@ -33,6 +33,8 @@ enum Hook {
   kHookQueryEarly,      // QUERY_EARLY      0 = the query kernel's round-1..4 order (rows requested after
                         //                  the membership test); 1 = early rows where the layout allows
   kHookMergeEarly,      // MERGE_EARLY      the same switch for the merge kernel
+  kHookQueryLdsPad,     // QUERY_LDS_PAD    extra bytes of LDS per wave of the early-rows query kernels
+  kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = visited rings of 480 keys stay in LDS (early-rows kernels)
   kHookCount
 };
 

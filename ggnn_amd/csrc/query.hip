@@ -1,6 +1,8 @@
 // query kernel: best-first graph traversal, one wave64 per query.
 // Reference: QueryKernel::operator(), src/ggnn/query/query_layer.cu:39-97; host sizing
 // QueryKernelsImpl::query, src/ggnn/query/query_kernels.cu:50-186.
+#include <algorithm>
+
 #include "traversal.hpp"
 #include "query_args.hpp"
 
@@ -19,24 +21,26 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 #ifndef GGNN_QUERY_WAVES
 #define GGNN_QUERY_WAVES 7
 #endif
-// early rows + pre-screen: the requested code rows (15 registers) are live across the pop's
-// bookkeeping and the membership test; 72 registers spill 4-11 of them, 80 (6 waves) none
-#ifndef GGNN_QUERY_WAVES_EARLY
-#define GGNN_QUERY_WAVES_EARLY 6
+// early rows: the requested code rows (15 registers) are live across the pop's bookkeeping and the
+// membership test; with the float query row in LDS (DistEngine<.., QL>) the kernels still fit the
+// 72 registers of 7 waves.  The global-ring variants spill 9-15 registers there: 80 (6 waves; they
+// exist for caches whose LDS ring would allow fewer)
+#ifndef GGNN_QUERY_WAVES_GR
+#define GGNN_QUERY_WAVES_GR 6
 #endif
 
 // EARLY (R = 1, KBuild <= 24; traversal.hpp "Early rows"): the first-read rows of a pop's neighbours
 // are requested before the pop's bookkeeping and the membership test instead of after them.
-template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0, bool EARLY = false>
+// GR (with EARLY and a hashed set): the visited ring in global memory (SortedList<R, HB, true>).
+template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0, bool EARLY = false,
+          bool GR = false>
 __global__ void __launch_bounds__(kWave) __attribute__((
-    amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? ((EARLY && PSC::enabled) ? GGNN_QUERY_WAVES_EARLY
-                                                                        : GGNN_QUERY_WAVES)
-                                             : 1)))
+    amdgpu_waves_per_eu((R == 1 && NCH <= 3) ? (GR ? GGNN_QUERY_WAVES_GR : GGNN_QUERY_WAVES) : 1)))
 query_kernel(const QueryArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   // tag-set form: the visited ring is not in LDS, the candidate scratch follows the sorted keys
-  const WaveLds lds(lds_raw, is_tag_set(HB) ? a.sorted : a.cache);
+  const WaveLds lds(lds_raw, (is_tag_set(HB) || GR) ? a.sorted : a.cache);
   const int lane = threadIdx.x;
   const uint32_t n = block_linear_index();
   if (n >= a.Nq)
@@ -54,12 +58,15 @@ query_kernel(const QueryArgs a)
   using DE = DistEngine<BaseT, LPR, NCH, EARLY && PSC::enabled>;
   DE de;
   de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D,
-                               lds_raw + wave_lds_ints(is_tag_set(HB) ? a.sorted : a.cache, HB));
+                               lds_raw + wave_lds_ints((is_tag_set(HB) || GR) ? a.sorted : a.cache, HB));
   PSC ps;
   load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
-  SortedList<R, HB> sl;
-  if constexpr (is_tag_set(HB))
+  SortedList<R, HB, GR> sl;
+  if constexpr (GR)
+    sl.init_global_ring(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots),
+                        a.ring + static_cast<size_t>(n) * (a.cache - a.sorted));
+  else if constexpr (is_tag_set(HB))
     sl.init_tagged(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots),
                    a.ring + static_cast<size_t>(n) * (a.cache - a.sorted));
   else
@@ -278,10 +285,18 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
     // registers, and a scratch reload waits for vmcnt(0), i.e. for the rows just requested)
     const bool tagged = hb == 0 && fits && args.ring && (args.tag_bits == 8 || args.tag_bits == 9);
     if (args.KBuild <= 8 * kEarlySteps && sorted <= 64 && !tagged && hook(kHookQueryEarly) != 0) {
-      constexpr size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes;
+      // (hook QUERY_LDS_PAD: extra bytes of LDS per wave -- occupancy experiments without a rebuild)
+      const size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes +
+                          static_cast<size_t>(std::clamp<int64_t>(hook(kHookQueryLdsPad), 0, 32768));
       if (hb == 1)
         hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1, true>), grid_for(args.Nq),
                            dim3(kWave), wave_lds_bytes(args.cache, 1) + qrow, stream, args);
+      else if (hb == 2 && args.ring && args.tag_bits == 0)
+        // caches of 512 keys: their 2 KB ring would limit the occupancy -- it lives in global
+        // memory when the search cannot wrap it (launch_query allocates it then)
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2, true, true>),
+                           grid_for(args.Nq), dim3(kWave), wave_lds_bytes(sorted, 2) + qrow, stream,
+                           args);
       else if (hb == 2)
         hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2, true>), grid_for(args.Nq),
                            dim3(kWave), wave_lds_bytes(args.cache, 2) + qrow, stream, args);
@@ -404,8 +419,14 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.vis_slots = vis_slots_hook();
   // long rings: per-query visited rings as stream-ordered scratch of this launch
   const uint32_t vis = args.cache - args.sorted;
-  if (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0) {
-    args.tag_bits = tag_set_bucket_bits(vis);
+  // global ring next to the two-register hashed set (launch_query_r: early rows, cache = 512) when
+  // the search cannot wrap it (hook QUERY_GLOBAL_RING = 0: ring in LDS, A/B and test hook)
+  const bool global_ring = args.sorted <= 64 && vis_hash_regs(vis) == 2 && a.max_iterations <= vis &&
+                           a.KBuild <= 8 * kEarlySteps && hook(kHookQueryEarly) != 0 &&
+                           hook(kHookQueryGlobalRing) != 0;
+  if (global_ring ||
+      (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0)) {
+    args.tag_bits = global_ring ? 0 : tag_set_bucket_bits(vis);
     try {
       args.ring = static_cast<int32_t*>(
           scratch_alloc(static_cast<size_t>(a.Nq) * vis * sizeof(int32_t), stream));

@@ -250,9 +250,17 @@ inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
 //     of the search -- the ring is always maintained, so the answer is exact in every case;
 //   * when the ring wraps (more pops than ring entries) the overwritten key is removed again.
 // The set of keys reported as known is exactly the reference's: sorted part + visited ring.
-template <int R, int HB = 0>
+// GR (with HB > 0): the visited ring itself lives in GLOBAL memory as in the tag-set form (one
+// store per pop, read only if the set overflows), so a wave's LDS holds only the sorted keys, the
+// scratch and the buckets -- for kernels whose occupancy the 2 KB ring of a 512-key cache limits.
+// The set's keys are never removed then: meant for searches that cannot wrap the ring
+// (max_iterations <= ring length, the launcher's condition); a wrap would switch to the scan of
+// the global ring (exact, slow).
+template <int R, int HB = 0, bool GR = false>
 struct SortedList {
+  static_assert(!GR || HB > 0, "global ring: only next to the hashed set");
   static constexpr int kHashRegs = HB;
+  static constexpr bool kGlobalRing = is_tag_set(HB) || GR;
   static constexpr int NB = 64 * HB;
   int key[R];
   float dist[R];
@@ -290,6 +298,21 @@ struct SortedList {
     hstash = hbuckets + NB * kVisSlots;
     reset(known);
   }
+  // global-ring form of the hashed set: only known[0, sorted) lives in LDS (WaveLds(base, sorted))
+  GGNN_DEV void init_global_ring(int best, int sorted, int cache, float xi_, int* known,
+                                 int usable_slots, int* ring)
+  {
+    BEST = best;
+    SORTED = sorted;
+    P = sorted - best;
+    VIS = cache - sorted;
+    xi = xi_;
+    slots = usable_slots;
+    ring_g = ring;
+    hbuckets = known + sorted + static_cast<int>(WaveLds::extra_ints);
+    hstash = hbuckets + NB * kVisSlots;
+    reset(known);
+  }
   // tag-set form: only known[0, sorted) lives in LDS (WaveLds(base, sorted)); the ring is ring
   GGNN_DEV void init_tagged(int best, int sorted, int cache, float xi_, int* known, int usable_slots,
                             int* ring)
@@ -320,8 +343,10 @@ struct SortedList {
       scan_mode = 0;
       return;
     }
-    for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
-      known[i] = kEmptyKey;
+    if constexpr (!GR) {
+      for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
+        known[i] = kEmptyKey;
+    }
     if constexpr (HB > 0) {
       int4* hb = reinterpret_cast<int4*>(hbuckets);
       for (int i = threadIdx.x; i < NB * kVisSlots / 4; i += kWave)
@@ -601,18 +626,26 @@ struct SortedList {
   }
   GGNN_DEV void pop_commit(const int k0, int* known)
   {
-    if constexpr (HB > 0) {
+    if constexpr (HB > 0 && !GR) {
       if (!scan_mode) {
         if (vis_count == VIS)  // the ring wraps: its oldest key is forgotten
           vis_remove(uni(known[SORTED + vis_head]));
         vis_insert(k0);
       }
     }
+    if constexpr (GR) {
+      if (vis_count == VIS)
+        scan_mode = 1;  // the ring wraps (keys are never removed here): the ring scan takes over
+      if (!scan_mode)
+        vis_insert(k0);
+    }
     if constexpr (kTag) {
       if (vis_count == VIS)
         scan_mode = 1;  // the ring wraps (tags are never removed): the ring scan takes over
       if (!scan_mode)
         tag_insert(k0);
+    }
+    if constexpr (kGlobalRing) {
       if (threadIdx.x == 0)
         ring_g[vis_head] = k0;
     }
@@ -677,6 +710,31 @@ struct SortedList {
 
   // filter part of fetch(): simple_knn_cache.cuh:246-261 / simple_knn_sym_cache.cuh:408-419.
   // cand: lanes j and j+32 hold candidate j (or EMPTY).  Returns cand with known keys blanked.
+  // rare: the ring in global memory is scanned, 16 bytes per lane and step, both half-waves.
+  // The keys were stored by lane 0 of this wave and another lane's store does not update the
+  // vector L1: it is invalidated first (agent-scope acquire)
+  GGNN_DEV unsigned scan_global_ring(unsigned acc, const unsigned c, const int h) const
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int4* rp = reinterpret_cast<const int4*>(ring_g);
+    const int steps = (vis_count + 3) >> 2;  // the ring length is a multiple of four
+    // (one step in flight: more would cost the whole kernel registers for a path that runs
+    // for the last few pops of a search, if at all)
+    for (int t = h; t < steps; t += 2) {
+      int4 e = rp[t];
+      if (t * 4 + 1 >= vis_count)
+        e.y = kEmptyKey;
+      if (t * 4 + 2 >= vis_count)
+        e.z = kEmptyKey;
+      if (t * 4 + 3 >= vis_count)
+        e.w = kEmptyKey;
+      acc = min(min(acc, static_cast<unsigned>(e.x) ^ c), static_cast<unsigned>(e.y) ^ c);
+      acc = min(min(acc, static_cast<unsigned>(e.z) ^ c), static_cast<unsigned>(e.w) ^ c);
+    }
+    return acc;
+  }
+
   // AHEAD: the reads of the next pair of 16-byte groups are issued before the current pair is
   // folded (a lone wave otherwise pays one LDS latency per pair).  The early-rows order runs the
   // test under the latency of the candidates' row loads and prefers the 8 registers.
@@ -694,7 +752,7 @@ struct SortedList {
     __syncthreads();
     // with the hashed set only the sorted part is scanned; the visited ring is one bucket read
     const bool hashed = (HB != 0) && !scan_mode;
-    const int E = (hashed || kTag) ? SORTED : SORTED + vis_count;
+    const int E = (hashed || kGlobalRing) ? SORTED : SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
     // min over (entry XOR cand) is 0 iff some entry equals cand.  Pure VALU on purpose: the
@@ -729,27 +787,12 @@ struct SortedList {
             acc1 = min(acc1, static_cast<unsigned>(hstash[t]) ^ c);
         }
       }
-      else {
-        // rare: the ring in global memory is scanned, 16 bytes per lane and step, both half-waves.
-        // The keys were stored by lane 0 of this wave and another lane's
-        // store does not update the vector L1: it is invalidated first (agent-scope acquire)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int4* rp = reinterpret_cast<const int4*>(ring_g);
-        const int steps = (vis_count + 3) >> 2;  // the ring length is a multiple of four
-        // (one step in flight: more would cost the whole kernel registers for a path that runs
-        // for the last few pops of a search, if at all)
-        for (int t = h; t < steps; t += 2) {
-          int4 e = rp[t];
-          if (t * 4 + 1 >= vis_count)
-            e.y = kEmptyKey;
-          if (t * 4 + 2 >= vis_count)
-            e.z = kEmptyKey;
-          if (t * 4 + 3 >= vis_count)
-            e.w = kEmptyKey;
-          acc1 = fold(acc1, e);
-        }
-      }
+      else
+        acc1 = scan_global_ring(acc1, c, h);
+    }
+    if constexpr (GR) {
+      if (!hashed)
+        acc1 = scan_global_ring(acc1, c, h);
     }
     if constexpr (HB > 0) {
       if (hashed) {
@@ -1512,8 +1555,8 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
 // Candidate s*8 + grp goes to the eight lanes of group grp in step s (ds_bpermute), so there is no
 // compaction in front of the loads; known candidates are read too (21.4 of 24 survive the test
 // anyway) and are masked out afterwards.  Decisions, counters and results are those of fetch():
-// the set of evaluated candidates, their order and the criteria they meet are unchanged; only the
-// row counters (rows actually read) see the <= 24 requested rows instead of the survivors.
+// the set of evaluated candidates, their order and the criteria they meet are unchanged (the row
+// counters keep counting what the algorithm needs, not the extra rows of known candidates).
 // ---------------------------------------------------------------------------------------------
 constexpr int kEarlySteps = 3;  // 24 candidates
 template <class RD>  // RD: the reader of the first rows (Prescreen<8,1,.> or DistEngine<.,8,1>)
@@ -1526,18 +1569,33 @@ struct EarlyRows {
   GGNN_DEV void issue(const RD& rd, const int cand, const int32_t* translation = nullptr)
   {
     const int grp = threadIdx.x >> 3;
+    // the three crossbar reads first (one wait for all of them, not one round trip per step)
+#pragma unroll
+    for (int s = 0; s < kEarlySteps; ++s)
+      kk[s] = __builtin_amdgcn_ds_bpermute((s * 8 + grp) << 2, cand);
+    int m[kEarlySteps];
 #pragma unroll
     for (int s = 0; s < kEarlySteps; ++s) {
-      kk[s] = __builtin_amdgcn_ds_bpermute((s * 8 + grp) << 2, cand);
       // EMPTY slots read row 0 (verdict ignored): no branch and no zero-fill around the loads
-      int m = max(kk[s], 0);
+      m[s] = max(kk[s], 0);
       if (translation)
-        m = translation[m];
-      const auto* row = rd.row_ptr(m);
-      if (rd.all_chunks || rd.chunk_valid(0))
-        v[s][0] = rd.load_chunk(row, 0);
-      else
-        v[s][0] = typename RD::Chunk{};
+        m[s] = translation[m[s]];
+    }
+    // ONE wave-uniform branch for "every lane's chunk lies inside the row" (the common shapes)
+    // instead of an exec-mask region and a zero-fill around each of the three loads
+    if (rd.all_chunks) {
+#pragma unroll
+      for (int s = 0; s < kEarlySteps; ++s)
+        v[s][0] = rd.load_chunk(rd.row_ptr(m[s]), 0);
+    }
+    else {
+#pragma unroll
+      for (int s = 0; s < kEarlySteps; ++s) {
+        if (rd.chunk_valid(0))
+          v[s][0] = rd.load_chunk(rd.row_ptr(m[s]), 0);
+        else
+          v[s][0] = typename RD::Chunk{};
+      }
     }
   }
 };
@@ -1552,18 +1610,21 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
   const int lane = threadIdx.x;
   const int grp = lane >> 3;
   const bool g0 = (lane & 7) == 0;
-  const unsigned requested =
-      static_cast<unsigned>(__popcll(__ballot(lane < 8 * kEarlySteps && cand != kEmptyKey)));
   cand = sl.template filter<false>(lower_half_to_both(cand), lds.known);
   const unsigned surv = static_cast<unsigned>(__ballot(lane < 32 && cand != kEmptyKey));
   const int nsurv = __popc(surv);
   after_filter();
+  // rows.x / rows.y count the rows the ALGORITHM needs, as fetch() does (code rows of the
+  // survivors of the membership test while the pre-screen is active, float rows of those that pass
+  // it): the roofline's algorithmic bytes do not grow because this order also requests the rows of
+  // the ~11 % known candidates (measured fabric traffic shows those)
   if constexpr (PS::enabled) {
-    rows.y += requested;
     if (nsurv == 0)
       return 0;
     // +inf (list not full yet, pre-screen unusable): nothing is dropped, every survivor is evaluated
     const float s_thr = ps.threshold(sl.criteria());
+    if (s_thr < inf_f())
+      rows.y += nsurv;
     int neval = 0;
 #pragma unroll
     for (int s = 0; s < kEarlySteps; ++s) {
@@ -1599,7 +1660,7 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
   else {
     // the requested rows ARE the base rows: distances stay in the lanes that summed them (lane
     // grp*8 of step s = candidate s*8 + grp), the replay reads them from there in candidate order
-    rows.x += requested;
+    rows.x += nsurv;
     if (nsurv == 0)
       return 0;
     float dd[kEarlySteps];

@@ -250,7 +250,12 @@ void ggnn_set_log_level(int level);
  *                             pop's neighbours (pre-screen codes, or rows of <= 128 bytes) are
  *                             requested BEFORE the pop's bookkeeping and the membership test;
  *                             0 = after them (the order of rounds 1-4; same results)
- *   MERGE_EARLY         1     the same switch for the merge kernel */
+ *   MERGE_EARLY         1     the same switch for the merge kernel
+ *   QUERY_LDS_PAD       0     extra bytes of LDS per wave of the early-rows query kernels (lowers the
+ *                             occupancy: measurements of its effect without a rebuild)
+ *   QUERY_GLOBAL_RING   1     early-rows query kernels with a cache of 512 keys (257..480 iterations):
+ *                             1 = the visited ring lives in global memory (its 2 KB of LDS per wave
+ *                             limit the occupancy) whenever the search cannot wrap it; 0 = in LDS */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);

@@ -15,7 +15,14 @@ from ggnn_amd import _lib
 
 ggnn.set_log_level(-1)
 n, d, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-points = [tuple(float(x) for x in p.split(":")) for p in sys.argv[4:]] or [(0.85, 175)]
+rest = sys.argv[4:]
+# hook combinations to compare: --combos "QUERY_EARLY=0;QUERY_EARLY=1,QUERY_GLOBAL_RING=0;..."
+combos = [{"QUERY_EARLY": 0}, {"QUERY_EARLY": 1}]
+if rest and rest[0] == "--combos":
+    combos = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv)
+              for c in rest[1].split(";")]
+    rest = rest[2:]
+points = [tuple(float(x) for x in p.split(":")) for p in rest] or [(0.85, 175)]
 dev = torch.device("cuda", 0)
 base = synthetic("lowrank16", n, d, 1234, dev)
 qs = {"tune": synthetic("lowrank16", 10_000, d, 4321, dev),
@@ -57,22 +64,22 @@ rows = []
 for tau, it in points:
     it = int(it)
     row = {"tau": tau, "it": it}
-    res = {}
-    for early in (0, 1):
-        with _lib.hooks(QUERY_EARLY=early):
+    res = []
+    for ci, combo in enumerate(combos):
+        with _lib.hooks(**combo):
             eng.set_collect_counters(True)
             ids, dists = eng.query(qs["tune"], 10, tau, it)
             cnt, rr = eng.last_query_counters(), eng.last_query_rows_read()
             eng.set_collect_counters(False)
             ms10, _ = timed(qs["tune"], tau, it, 10)
             ms100, _ = timed(big, tau, it, 3)
-            res[early] = (ids.clone(), dists.clone(), cnt)
-            row[f"ms10k_e{early}"] = round(ms10, 4)
-            row[f"ms100k_e{early}"] = round(ms100, 3)
-            row[f"rows_e{early}"] = rr
-    row["identical"] = bool(torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-                            and res[0][2] == res[1][2])
-    row["counters"] = res[1][2]
+            res.append((ids.clone(), dists.clone(), cnt, rr))
+            tag = ",".join(f"{k}={v}" for k, v in combo.items()) or "default"
+            row[tag] = {"ms10k": round(ms10, 4), "ms100k": round(ms100, 3)}
+    row["identical"] = all(bool(torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
+                                and r[2] == res[0][2] and r[3] == res[0][3]) for r in res)
+    row["counters"] = res[0][2]
+    row["rows"] = res[0][3]
     row["recall"] = {k: round(recall_at_k(eng.query(q, 10, tau, it)[0], gts[k]), 4)
                      for k, q in qs.items()}
     rows.append(row)

@@ -153,7 +153,8 @@ def test_query_int_exact(ops, orc, small_graph, K, tau, iters):
 @pytest.mark.parametrize("K,tau,iters", [(10, 0.64, 200), (10, 2.5, 250), (24, 3.0, 255),
                                          (10, 0.64, 400), (10, 3.0, 512), (40, 3.0, 500),
                                          (10, 4.0, 1000), (10, 0.8, 1024), (10, 5.0, 2048),
-                                         (10, 1.0, 1500)])
+                                         (10, 1.0, 1500), (10, 3.0, 480), (40, 3.0, 448),
+                                         (10, 3.0, 300)])
 def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, iters, monkeypatch):
     g = small_graph
     q = make_int_data(96, g["D"], 4322)
@@ -174,6 +175,11 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the 192-entry ring"
     if iters in (500, 512):
         assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
+    # 257..480 iterations that cannot wrap their ring (480 / 448 keys): the early-rows kernel keeps
+    # the ring in GLOBAL memory (SortedList<1, 2, true>); 1-2 usable slots overflow the stash there,
+    # i.e. the membership test scans the global ring for the rest of the search
+    if iters in (480, 448):
+        assert int(o_np.max()) > 400, "the case is meant to fill most of its ring"
     # 1000..2048 iterations: rings of 992 / 2016 keys kept in global memory and mirrored in the
     # 16-bit tag set (traversal.hpp kTagSet): 1-2 usable slots overflow the stash (the scan of the
     # global ring takes over), 4 fill it; 1000 / 1024 iterations on a 992-key ring wrap it
@@ -181,6 +187,54 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
         assert int(o_np.max()) > 900, "the case is meant to fill the 992-entry ring"
     if (tau, iters) == (5.0, 2048):
         assert int(o_np.max()) > 1500, "the case is meant to go deep into the 2016-entry ring"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("K,tau,iters", [(10, 0.64, 175), (10, 0.9, 400), (40, 2.0, 448),
+                                         (10, 3.0, 256), (10, 1.0, 480)])
+def test_query_orders_and_ring_homes_equal_the_oracle(ops, orc, small_graph, dtype, K, tau, iters):
+    """The query kernel's order variants (hook QUERY_EARLY: first-read rows of a pop's neighbours
+    requested before / after the pop's bookkeeping and the membership test; hook
+    QUERY_GLOBAL_RING: visited ring of a 512-key cache in global memory / in LDS) against the
+    oracle: ids, distances, n_dist, n_pop -- float32 with the pre-screen and uint8 rows (the two
+    early-rows layouts)."""
+    from ggnn_amd import _lib
+    g = small_graph
+    base = g["base"] if dtype == "f32" else g["base"].astype(np.uint8)
+    q = make_int_data(80, g["D"], 4324)
+    q = q if dtype == "f32" else q.astype(np.uint8)
+    graph0 = g["graph"][:g["N"]]
+    o_ids, o_d, o_nd, o_np = orc.query(base, q, graph0, start_points(g), g["stats"], K, tau, iters,
+                                       counters=True)
+    b = dev(base)
+    ps = ops.prescreen_encode(b) if dtype == "f32" else None
+    for early, gring in ((1, 1), (1, 0), (0, 1)):
+        with _lib.hooks(QUERY_EARLY=early, QUERY_GLOBAL_RING=gring):
+            ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start_points(g)),
+                                         dev(g["stats"]), K, tau, iters, counters=True, prescreen=ps)
+        assert np.array_equal(ids.cpu().numpy(), o_ids), (early, gring)
+        assert np.array_equal(d.cpu().numpy(), o_d), (early, gring)
+        assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), (early, gring)
+        assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), (early, gring)
+
+
+@pytest.mark.parametrize("top,btm", [(3, 0), (2, 0), (2, 1)])
+def test_merge_orders_equal_the_oracle(ops, orc, small_graph, top, btm):
+    """hook MERGE_EARLY = 1 | 0 (the same reordering in the merge kernel, upper layers go through
+    the translation) with and without the pre-screen"""
+    from ggnn_amd import _lib
+    g = small_graph
+    c = g["cfg"]
+    o_gb, o_nn1 = orc.merge(g["base"], c, g["graph"], g["tr"], g["sel"], g["stats"], 0.5, top, btm)
+    b = dev(g["base"])
+    for early in (1, 0):
+        for ps in (None, ops.prescreen_encode(b)):
+            with _lib.hooks(MERGE_EARLY=early):
+                gb, nn1 = ops.merge(b, c, dev(g["graph"]), dev(g["tr"]), dev(g["sel"]),
+                                    dev(g["stats"]), 0.5, top, btm, prescreen=ps)
+            assert np.array_equal(gb.cpu().numpy(), o_gb), (early, ps is not None)
+            if btm == 0:
+                assert np.array_equal(nn1.cpu().numpy(), o_nn1), (early, ps is not None)
 
 
 @pytest.mark.parametrize("K,tau,iters", [(10, 4.0, 1000), (10, 6.0, 1024), (30, 5.0, 2048),
