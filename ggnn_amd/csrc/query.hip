@@ -26,7 +26,7 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 // 72 registers of 7 waves.  The global-ring variants spill 9-15 registers there: 80 (6 waves; they
 // exist for caches whose LDS ring would allow fewer)
 #ifndef GGNN_QUERY_WAVES_GR
-#define GGNN_QUERY_WAVES_GR 6
+#define GGNN_QUERY_WAVES_GR 7
 #endif
 
 // EARLY (R = 1, KBuild <= 24; traversal.hpp "Early rows"): the first-read rows of a pop's neighbours

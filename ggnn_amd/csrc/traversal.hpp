@@ -250,17 +250,23 @@ inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
 //     of the search -- the ring is always maintained, so the answer is exact in every case;
 //   * when the ring wraps (more pops than ring entries) the overwritten key is removed again.
 // The set of keys reported as known is exactly the reference's: sorted part + visited ring.
-// GR (with HB > 0): the visited ring itself lives in GLOBAL memory as in the tag-set form (one
-// store per pop, read only if the set overflows), so a wave's LDS holds only the sorted keys, the
-// scratch and the buckets -- for kernels whose occupancy the 2 KB ring of a 512-key cache limits.
-// The set's keys are never removed then: meant for searches that cannot wrap the ring
-// (max_iterations <= ring length, the launcher's condition); a wrap would switch to the scan of
-// the global ring (exact, slow).
+// GR (with HB > 0): NO visited ring at all -- for searches that cannot wrap it (max_iterations <=
+// ring length, the launcher's condition) the ring's only job is to say which keys are known, and
+// the buckets + stash hold exactly those keys (nothing is ever removed without a wrap).  A wave's
+// LDS then holds only the sorted keys, the scratch and the buckets: for kernels whose occupancy
+// the 2 KB ring of a 512-key cache limits.  A key that fits neither its bucket nor the stash goes
+// to an overflow list in global memory (`ring_g`, normally empty; every probe scans it when it is
+// not).  (First version: the ring itself in global memory, one store per pop -- slower than the
+// LDS ring at higher occupancy, 3.69 vs 3.38 ms on the 12.5M x 96 shard: with a store in flight
+// the compiler can no longer wait for "all but the newest n" loads -- loads and stores retire out
+// of order with respect to each other -- so every wait for the requested code rows became
+// vmcnt(0) and also waited for the speculative graph row issued after them.)
 template <int R, int HB = 0, bool GR = false>
 struct SortedList {
   static_assert(!GR || HB > 0, "global ring: only next to the hashed set");
   static constexpr int kHashRegs = HB;
-  static constexpr bool kGlobalRing = is_tag_set(HB) || GR;
+  static constexpr bool kGlobalRing = is_tag_set(HB);
+  int ovf_n;                  // GR: keys in the overflow list (global memory)
   static constexpr int NB = 64 * HB;
   int key[R];
   float dist[R];
@@ -298,7 +304,8 @@ struct SortedList {
     hstash = hbuckets + NB * kVisSlots;
     reset(known);
   }
-  // global-ring form of the hashed set: only known[0, sorted) lives in LDS (WaveLds(base, sorted))
+  // ring-less form of the hashed set: only known[0, sorted) lives in LDS (WaveLds(base, sorted));
+  // ring: this search's overflow list, (cache - sorted) ints of global memory
   GGNN_DEV void init_global_ring(int best, int sorted, int cache, float xi_, int* known,
                                  int usable_slots, int* ring)
   {
@@ -343,6 +350,7 @@ struct SortedList {
       scan_mode = 0;
       return;
     }
+    ovf_n = 0;
     if constexpr (!GR) {
       for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
         known[i] = kEmptyKey;
@@ -404,6 +412,11 @@ struct SortedList {
       if (threadIdx.x == 0)
         hstash[stash_n] = k;
       ++stash_n;
+    }
+    else if constexpr (GR) {
+      if (threadIdx.x == 0)
+        ring_g[ovf_n] = k;  // (at most one entry per pop, pops <= ring length)
+      ++ovf_n;
     }
     else
       scan_mode = 1;  // the ring scan takes over; the set is no longer maintained
@@ -633,12 +646,8 @@ struct SortedList {
         vis_insert(k0);
       }
     }
-    if constexpr (GR) {
-      if (vis_count == VIS)
-        scan_mode = 1;  // the ring wraps (keys are never removed here): the ring scan takes over
-      if (!scan_mode)
-        vis_insert(k0);
-    }
+    if constexpr (GR)
+      vis_insert(k0);  // (no wrap: pops <= max_iterations <= ring length)
     if constexpr (kTag) {
       if (vis_count == VIS)
         scan_mode = 1;  // the ring wraps (tags are never removed): the ring scan takes over
@@ -649,8 +658,10 @@ struct SortedList {
       if (threadIdx.x == 0)
         ring_g[vis_head] = k0;
     }
-    else if (threadIdx.x == 0)
-      known[SORTED + vis_head] = k0;
+    else if constexpr (!GR) {
+      if (threadIdx.x == 0)
+        known[SORTED + vis_head] = k0;
+    }
     vis_head = (vis_head + 1 >= VIS) ? 0 : vis_head + 1;
     vis_count = (vis_count + 1 > VIS) ? VIS : vis_count + 1;
     const int lane = threadIdx.x;
@@ -713,21 +724,22 @@ struct SortedList {
   // rare: the ring in global memory is scanned, 16 bytes per lane and step, both half-waves.
   // The keys were stored by lane 0 of this wave and another lane's store does not update the
   // vector L1: it is invalidated first (agent-scope acquire)
-  GGNN_DEV unsigned scan_global_ring(unsigned acc, const unsigned c, const int h) const
+  // count: valid entries at the head of ring_g
+  GGNN_DEV unsigned scan_global_ring(unsigned acc, const unsigned c, const int h, const int count) const
   {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int4* rp = reinterpret_cast<const int4*>(ring_g);
-    const int steps = (vis_count + 3) >> 2;  // the ring length is a multiple of four
+    const int steps = (count + 3) >> 2;  // the ring length is a multiple of four
     // (one step in flight: more would cost the whole kernel registers for a path that runs
     // for the last few pops of a search, if at all)
     for (int t = h; t < steps; t += 2) {
       int4 e = rp[t];
-      if (t * 4 + 1 >= vis_count)
+      if (t * 4 + 1 >= count)
         e.y = kEmptyKey;
-      if (t * 4 + 2 >= vis_count)
+      if (t * 4 + 2 >= count)
         e.z = kEmptyKey;
-      if (t * 4 + 3 >= vis_count)
+      if (t * 4 + 3 >= count)
         e.w = kEmptyKey;
       acc = min(min(acc, static_cast<unsigned>(e.x) ^ c), static_cast<unsigned>(e.y) ^ c);
       acc = min(min(acc, static_cast<unsigned>(e.z) ^ c), static_cast<unsigned>(e.w) ^ c);
@@ -752,7 +764,7 @@ struct SortedList {
     __syncthreads();
     // with the hashed set only the sorted part is scanned; the visited ring is one bucket read
     const bool hashed = (HB != 0) && !scan_mode;
-    const int E = (hashed || kGlobalRing) ? SORTED : SORTED + vis_count;
+    const int E = (hashed || kGlobalRing || GR) ? SORTED : SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
     // min over (entry XOR cand) is 0 iff some entry equals cand.  Pure VALU on purpose: the
@@ -788,11 +800,18 @@ struct SortedList {
         }
       }
       else
-        acc1 = scan_global_ring(acc1, c, h);
+        acc1 = scan_global_ring(acc1, c, h, vis_count);
     }
     if constexpr (GR) {
-      if (!hashed)
-        acc1 = scan_global_ring(acc1, c, h);
+      // overflow list (normally empty): one key at a time -- this rare path must not add to the
+      // register peak of the test, which the requested code rows of the early-rows order share.
+      // The keys were stored by lane 0: the vector L1 is invalidated first.
+      if (ovf_n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int t = 0; t < ovf_n; ++t)
+          acc1 = min(acc1, static_cast<unsigned>(ring_g[t]) ^ c);
+      }
     }
     if constexpr (HB > 0) {
       if (hashed) {
