@@ -34,7 +34,7 @@ enum Hook {
                         //                  the membership test); 1 = early rows where the layout allows
   kHookMergeEarly,      // MERGE_EARLY      the same switch for the merge kernel
   kHookQueryLdsPad,     // QUERY_LDS_PAD    extra bytes of LDS per wave of the early-rows query kernels
-  kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = visited rings of 480 keys stay in LDS (early-rows kernels)
+  kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = early-rows kernels keep a visited ring in LDS even when it cannot wrap
   kHookCount
 };
 

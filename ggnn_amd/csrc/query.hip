@@ -288,12 +288,17 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
       // (hook QUERY_LDS_PAD: extra bytes of LDS per wave -- occupancy experiments without a rebuild)
       const size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes +
                           static_cast<size_t>(std::clamp<int64_t>(hook(kHookQueryLdsPad), 0, 32768));
-      if (hb == 1)
+      // a search that cannot wrap its visited ring needs no ring: buckets + stash ARE the set
+      // (SortedList<R, HB, true>; launch_query allocates the overflow lists then)
+      const bool ringless = args.ring && args.tag_bits == 0;
+      if (hb == 1 && ringless)
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1, true, true>),
+                           grid_for(args.Nq), dim3(kWave), wave_lds_bytes(sorted, 1) + qrow, stream,
+                           args);
+      else if (hb == 1)
         hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 1, true>), grid_for(args.Nq),
                            dim3(kWave), wave_lds_bytes(args.cache, 1) + qrow, stream, args);
-      else if (hb == 2 && args.ring && args.tag_bits == 0)
-        // caches of 512 keys: their 2 KB ring would limit the occupancy -- it lives in global
-        // memory when the search cannot wrap it (launch_query allocates it then)
+      else if (hb == 2 && ringless)
         hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, 2, true, true>),
                            grid_for(args.Nq), dim3(kWave), wave_lds_bytes(sorted, 2) + qrow, stream,
                            args);
@@ -419,9 +424,9 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.vis_slots = vis_slots_hook();
   // long rings: per-query visited rings as stream-ordered scratch of this launch
   const uint32_t vis = args.cache - args.sorted;
-  // global ring next to the two-register hashed set (launch_query_r: early rows, cache = 512) when
-  // the search cannot wrap it (hook QUERY_GLOBAL_RING = 0: ring in LDS, A/B and test hook)
-  const bool global_ring = args.sorted <= 64 && vis_hash_regs(vis) == 2 && a.max_iterations <= vis &&
+  // ring-less hashed set (launch_query_r: early rows) when the search cannot wrap its ring: the
+  // overflow lists of the launch (hook QUERY_GLOBAL_RING = 0: ring in LDS, A/B and test hook)
+  const bool global_ring = args.sorted <= 64 && vis_hash_regs(vis) != 0 && a.max_iterations <= vis &&
                            a.KBuild <= 8 * kEarlySteps && hook(kHookQueryEarly) != 0 &&
                            hook(kHookQueryGlobalRing) != 0;
   if (global_ring ||

@@ -253,9 +253,10 @@ void ggnn_set_log_level(int level);
  *   MERGE_EARLY         1     the same switch for the merge kernel
  *   QUERY_LDS_PAD       0     extra bytes of LDS per wave of the early-rows query kernels (lowers the
  *                             occupancy: measurements of its effect without a rebuild)
- *   QUERY_GLOBAL_RING   1     early-rows query kernels with a cache of 512 keys (257..480 iterations):
- *                             1 = the visited ring lives in global memory (its 2 KB of LDS per wave
- *                             limit the occupancy) whenever the search cannot wrap it; 0 = in LDS */
+ *   QUERY_GLOBAL_RING   1     early-rows query kernels whose search cannot wrap its visited ring
+ *                             (max_iterations <= ring length): 1 = no ring at all, the hashed set's
+ *                             buckets and stash ARE the visited keys (overflow list in global
+ *                             memory); 0 = ring in LDS mirrored by the set */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);
