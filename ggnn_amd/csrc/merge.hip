@@ -129,16 +129,16 @@ __global__ void __launch_bounds__(kWave)
         const bool in_row = lane < static_cast<int>(K);  // K <= 24 (host)
         int cand;
         if (anchor == spec_key)
-          cand = spec_row;
+          cand = in_row ? spec_row : kEmptyKey;
         else
           cand = in_row ? layer_graph[static_cast<size_t>(static_cast<uint32_t>(anchor)) * K + lane]
                         : kEmptyKey;
+        // unconditional load, masked at the use (query.hip: a load under a branch turns the wait
+        // for the requested code rows into vmcnt(0))
         auto prefetch_head_row = [&]() {
           spec_key = sl.key_at(sl.BEST);
-          if (spec_key != kEmptyKey)
-            spec_row = in_row ? layer_graph[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
-                                                K + lane]
-                              : kEmptyKey;
+          spec_row = layer_graph[static_cast<size_t>(static_cast<uint32_t>(max(spec_key, 0))) * K +
+                                 min(lane, static_cast<int>(K) - 1)];
         };
         if constexpr (PSC::enabled) {
           EarlyRows<PSC> er;

@@ -105,16 +105,19 @@ query_kernel(const QueryArgs a)
       const bool in_row = lane < static_cast<int>(a.KBuild);  // KBuild <= 24 (host)
       int cand;
       if (anchor == spec_key)
-        cand = spec_row;
+        cand = in_row ? spec_row : kEmptyKey;
       else
         cand = in_row ? a.graph0[static_cast<size_t>(static_cast<uint32_t>(anchor)) * a.KBuild + lane]
                       : kEmptyKey;
+      // The speculative row is loaded UNCONDITIONALLY (an empty queue reads row 0, lanes past the
+      // row its last entry; masked where the row is consumed): a load under a branch leaves the
+      // two paths with different numbers of loads in flight, and the compiler then waits for the
+      // requested code rows with vmcnt(0) -- i.e. also for this load, issued a moment earlier
+      // (found in the ISA; the wait is vmcnt(1) now and the row travels during the verdicts).
       auto prefetch_head_row = [&]() {
         spec_key = sl.key_at(sl.BEST);
-        if (spec_key != kEmptyKey)
-          spec_row = in_row ? a.graph0[static_cast<size_t>(static_cast<uint32_t>(spec_key)) *
-                                           a.KBuild + lane]
-                            : kEmptyKey;
+        spec_row = a.graph0[static_cast<size_t>(static_cast<uint32_t>(max(spec_key, 0))) * a.KBuild +
+                            min(lane, static_cast<int>(a.KBuild) - 1)];
       };
       if constexpr (PSC::enabled) {
         EarlyRows<PSC> er;

@@ -842,6 +842,23 @@ struct SortedList {
       if (t < T)
         acc0 = fold(acc0, p[2 * t]);
     }
+    else if (R == 1 && E == 32) {
+      // one list register per lane: the sorted part has 32 or 64 keys, i.e. 4 or 8 groups of
+      // eight -- straight-line code instead of a loop with a run-time trip count (the loop's
+      // unrolled body, its remainder loops and their scalar bookkeeping cost more than the scan)
+#pragma unroll
+      for (int t = 0; t < 4; t += 2) {
+        acc0 = fold(acc0, p[2 * t]);
+        acc1 = fold(acc1, p[2 * t + 2]);
+      }
+    }
+    else if (R == 1 && E == 64) {
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) {
+        acc0 = fold(acc0, p[2 * t]);
+        acc1 = fold(acc1, p[2 * t + 2]);
+      }
+    }
     else {
       int t = 0;
       for (; t + 2 <= T; t += 2) {
