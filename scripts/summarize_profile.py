@@ -80,6 +80,37 @@ if sq:
                         "clock / 4 x 1024 SIMDs)",
                "kernels": sq}, open(f"{out_dir}/{tag}_pmc_sq.json", "w"), indent=1)
 
+# ---- SQ counters of the CONSTRUCTION kernels, summed over the launches of the profiled build ------
+# (bench.py build_roofline: which roof binds merge / sym -- fabric bytes vs HBM, own bytes vs the L2s,
+# VALU issue; the SQ cycle counters tick once per 4 clocks)
+build_sq = {}
+for n in ("sq1", "sq2"):
+    for r in counters(n):
+        k = r["Kernel_Name"]
+        for needle in ("merge_kernel", "sym_kernel"):
+            if "::" + needle + "<" in k:
+                e = build_sq.setdefault(needle, {"kernels": set(), "launches": {}, "dur_ns": {}})
+                e["kernels"].add(k.split("(")[0])
+                c = r["Counter_Name"]
+                e[c] = e.get(c, 0.0) + float(r["Counter_Value"])
+                e["launches"][c] = e["launches"].get(c, 0) + 1
+                e["dur_ns"][c] = e["dur_ns"].get(c, 0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+if build_sq:
+    for needle, e in build_sq.items():
+        e["kernels"] = sorted(e["kernels"])
+        ln = set(e["launches"].values())
+        e["launches"] = ln.pop() if len(ln) == 1 else e["launches"]
+        # duration under the profiler of the pass that counted SQ_ACTIVE_INST_VALU
+        e["duration_s_sq2_pass"] = e["dur_ns"].get("SQ_ACTIVE_INST_VALU", 0) * 1e-9
+        del e["dur_ns"]
+    json.dump({"workload": workload, "build_source_sha": BUILD_SHA,
+               "command": f"rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- {CMD} "
+                          "--steps 3 --warmup 1 (two passes; the command builds ONE graph)",
+               "units": "summed over every launch of the kernel family in one build; cycle counters "
+                        "tick once per 4 clocks: VALU issue fraction = SQ_ACTIVE_INST_VALU x 4 / "
+                        "(duration_s_sq2_pass x clock x 1024 SIMDs)",
+               "kernels": build_sq}, open(f"{out_dir}/{tag}_pmc_build_sq.json", "w"), indent=1)
+
 # ---- recomputable roofline fraction of this shape ------------------------------------------------
 try:
     rl = bench["roofline"]

@@ -66,3 +66,28 @@ def test_kernel_source_sha_is_stable_and_tracks_sources():
     import bench
     a = bench.kernel_source_sha()
     assert a == bench.kernel_source_sha() and len(a) == 16
+
+
+def test_operating_points_resolve_per_shape_and_command_line_wins():
+    """bench.py quotes `value` at a tuned (tau, iterations) per shape; explicit flags override"""
+    import bench
+    a = _args(tau_query=None, max_iters=None)
+    bench.resolve_operating_point(a, 1)
+    assert (a.tau_query, a.max_iters) == bench.OPERATING_POINTS[(1, 1_000_000, 128, "f32", "l2")][:2]
+    assert a.operating_point_source.startswith("OPERATING_POINTS")
+    # the N > 1 series: 8 shards of 12.5M x 96, tuned on MERGED recall
+    b = _args(tau_query=None, max_iters=None, n_base=12_500_000, dim=96)
+    bench.resolve_operating_point(b, bench.TOTAL_SHARDS)
+    assert (b.tau_query, b.max_iters) == bench.OPERATING_POINTS[(8, 12_500_000, 96, "f32", "l2")][:2]
+    one = _args(tau_query=None, max_iters=None, n_base=12_500_000, dim=96)
+    bench.resolve_operating_point(one, 1)
+    assert (one.tau_query, one.max_iters) != (b.tau_query, b.max_iters)   # a lone shard needs more
+    # an untuned shape falls back, an explicit flag is kept
+    c = _args(tau_query=None, max_iters=None, dim=960, measure="cosine")
+    bench.resolve_operating_point(c, 1)
+    assert (c.tau_query, c.max_iters) == bench.FALLBACK_POINT and "fallback" in c.operating_point_source
+    d = _args(tau_query=1.0, max_iters=None)
+    bench.resolve_operating_point(d, 1)
+    assert d.tau_query == 1.0 and d.operating_point_source == "command line"
+    # every tuned point states the recall it was confirmed at
+    assert all(len(v) == 3 and v[2] for v in bench.OPERATING_POINTS.values())

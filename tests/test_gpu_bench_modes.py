@@ -32,6 +32,7 @@ def test_bench_two_ranks_dry_run():
                "--n-base", "20000", "--secondary-n-base", "10000", "--n-query", "400",
                "--in-process-timeout", "300"])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["exchange"]["requested"] == "gloo" and out["exchange"]["fallback"] is False
     assert "160000 points" in out["config"]["workload"]
     assert out["recall_at_10"] > 0.9
     rl = out["roofline"]
@@ -49,6 +50,33 @@ def test_bench_two_ranks_dry_run():
     assert inproc["pipelined_batches"]["results_equal_blocking"] is True
     sec = out["secondary_base"]
     assert sec["n_base_per_shard"] == 10000 and sec["speedup_vs_one_gpu_same_base"]["blocking"] > 0
+
+
+def test_bench_two_ranks_rccl_is_attempted_and_falls_back_loudly():
+    """The driver launches `bench.py --gpus N` with the default `--backend nccl`.  On this one-GPU
+    box both ranks share device 0, which RCCL refuses: the exchange group's probe collective must
+    have been ATTEMPTED (requested == "nccl"), and the fallback to the host-staged gloo exchange
+    must be loud -- `exchange.fallback` with the reason in the line and a WARNING on stderr -- so
+    that a first run on real hardware cannot silently measure the copy path as "RCCL"."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "2",
+           "--steps", "3", "--warmup", "1", "--single-device", "--n-base", "20000",
+           "--secondary-n-base", "0", "--n-query", "400", "--no-in-process",
+           "--no-scaling-reference", "--no-pipelined"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    ex = out["exchange"]
+    assert ex["requested"] == "nccl"
+    if ex["fallback"]:      # one GPU: RCCL refuses two ranks on a device
+        assert ex["used"].startswith("gloo") and ex["reason"]
+        assert "WARNING" in r.stderr and "does NOT measure RCCL" in r.stderr
+    else:                   # (a box where the probe works: then the line must say RCCL)
+        assert "RCCL" in ex["used"]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["recall_at_10"] > 0.9
 
 
 def test_bench_lean_line_contract():

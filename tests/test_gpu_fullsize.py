@@ -40,13 +40,20 @@ def test_sift1m_shape_full_size(orc):
     gt, gt_d = eng.bf_query(query, K)
     assert eng.last_bf_query_rescanned() < Nq // 100
     eng.set_collect_counters(True)
-    ids, d = eng.query(query, K, 0.9, 175)
+    # the operating point bench.py quotes `value` at (its table, not a copy of it)
+    from bench import OPERATING_POINTS
+    tau, iters = OPERATING_POINTS[(1, N, D, "f32", "l2")][:2]
+    ids, d = eng.query(query, K, tau, iters)
     cnt = eng.last_query_counters()
     rows = eng.last_query_rows_read()
     assert recall_at_k(ids, gt) >= 0.99
+    # and on a query set the point was not tuned on
+    held = synthetic("lowrank16", Nq, D, 8642, dev)
+    assert recall_at_k(eng.query(held, K, tau, iters)[0], eng.bf_query(held, K)[0]) >= 0.99
+    eng.query(query, K, tau, iters)
     assert rows["code_rows"] > 0 and rows["float_rows"] < cnt["n_dist"] // 3   # pre-screen active
     eng.set_prescreen(False)
-    ids2, d2 = eng.query(query, K, 0.9, 175)
+    ids2, d2 = eng.query(query, K, tau, iters)
     assert eng.last_query_counters() == cnt
     assert torch.equal(ids, ids2) and torch.equal(d, d2)
     eng.set_prescreen(True)
@@ -62,10 +69,10 @@ def test_sift1m_shape_full_size(orc):
     start = g.translation[3].view.numpy().reshape(-1)
     stats = g.nn1_stats.view.numpy().reshape(-1)
     q_h = query[:200].cpu().numpy()
-    o_ids, o_d, o_nd, o_np = orc.query(b64, q_h, graph0, start, stats, K, 0.9, 175, counters=True)
+    o_ids, o_d, o_nd, o_np = orc.query(b64, q_h, graph0, start, stats, K, tau, iters, counters=True)
     assert np.array_equal(ids[:200].cpu().numpy(), o_ids)
     assert np.array_equal(d[:200].cpu().numpy(), o_d)
-    eng.query(query[:200].contiguous(), K, 0.9, 175)
+    eng.query(query[:200].contiguous(), K, tau, iters)
     c200 = eng.last_query_counters()
     assert c200["n_dist"] == int(o_nd.sum()) and c200["n_pop"] == int(o_np.sum())
 
@@ -244,9 +251,11 @@ def test_deep100m_shard_full_size(orc):
     """configs[3]: one of the 8 shards of DEEP100M, 12.5M x 96 f32.  G = 73 with SG = 0 and
     SG_off = 32: only the first 32 of each 73 lower segments promote a point (graph_config.cpp
     :94-97), a selection layout no smaller test reaches."""
+    from bench import OPERATING_POINTS
+    tau, iters = OPERATING_POINTS[(1, 12_500_000, 96, "f32", "l2")][:2]   # the bench's own point
     _shard_case(orc, 12_500_000, 96, torch.float32,
                 dict(G=73, S=32, S0=32, S0_off=51_456, SG=0, SG_off=32, N_all=12_672_896),
-                1.0, 400, check_prescreen=True)
+                tau, iters, check_prescreen=True)
 
 
 def test_sift1b_shard_full_size(orc):
