@@ -22,7 +22,9 @@ struct BfMfmaArgs {
   float* part_dists;   // [slices][Nq][KP]
   uint32_t D, Dh, DP, Nq, N_base, KP, slices, rows_per_slice;
   uint32_t DM;  // floats of the shift vector kept in LDS by the chunked kernel (D rounded up)
-  uint32_t* gthr;  // i8 v2 kernel: per-query bound shared by all slices (float bits), or null
+  uint32_t* gthr;  // i8 v2 kernel: exchange area of the slices' published set entries
+                   // ([Nq][5 ranks][slices padded to 4] ints, 0x7fffffff = none), or null
+  uint32_t rank_mask;  // which of the published positions are used (bit i = rank i)
   // float tile kernels, equal_ranges != 0: the (query block, unit) sequence is cut into equal
   // ranges, a unit being 32 rows (single chunk) or one accumulator group of T x 32 rows (chunked)
   uint32_t equal_ranges;
@@ -35,10 +37,10 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kBfI8RowStride = 144;
 
-// bf_i8.hip: launches bf_i8v2_kernel for KP in {4, 10, 16} (an optional seeding launch over the
-// head of the base first); m.gthr must point to Nq words initialised to +inf bits
-void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t warm_rows,
-                    hipStream_t stream);
+// bf_i8.hip: launches bf_i8v2_kernel for KP in {4, 10, 16}; m.gthr must point to
+// bf_i8v2_exchange_ints(Nq, slices) words initialised to 0x7fffffff (or be null: no exchange)
+void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipStream_t stream);
 size_t bf_i8v2_lds_bytes();
+size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices);
 
 }  // namespace ggnn_amd

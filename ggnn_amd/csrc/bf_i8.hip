@@ -6,6 +6,7 @@
 // instructions the tile test itself needs.
 // Reference being replaced: BruteForceQueryKernel, src/ggnn/query/bf_query_layer.cu:39-65.
 #include <cstdlib>
+#include <utility>
 
 #include "bf_common.hpp"
 
@@ -45,11 +46,12 @@ constexpr int kI8v2StageRows = 128;  // four 32-row tiles per barrier
 #define GGNN_I8_PEND 8
 #endif
 #ifndef GGNN_I8_REFRESH
-#define GGNN_I8_REFRESH 16
+#define GGNN_I8_REFRESH 64
 #endif
 constexpr int kI8v2Pend = GGNN_I8_PEND;         // pending candidates per query before a batch update
-constexpr int kI8v2Refresh = GGNN_I8_REFRESH;      // stages between exchanges of the shared bound
-                                                    // (2: 3.82 ms, 4: 3.54, 8-16: 3.42, 64: 3.50)
+constexpr int kI8v2Refresh = GGNN_I8_REFRESH;   // stages between exchanges once past the doubling phase
+                                                 // (single bound, rounds 3-4: every 2 stages 3.82 ms,
+                                                 //  4: 3.54, 8-16: 3.42, 64: 3.50)
 constexpr int kTeInf = 1 << 30;
 
 #ifdef GGNN_I8_STATS
@@ -64,6 +66,73 @@ __device__ unsigned long long g_i8_stats[16];
 #define I8_T0() do { } while (0)
 #define I8_T1(i) do { } while (0)
 #endif
+
+// ---- bound exchange between the slices of a query (round 5) ---------------------------------------
+// Round 3-4: every slice published the last entry of its K-best set and took the minimum over the
+// slices as an extra bound.  That bound is the best "K-th of ONE slice", i.e. about the 65th best
+// row seen by all 12 slices together, when the 10th would do -- and each slice starts cold.  Now a
+// slice publishes several POSITIONS p of its sorted set, and every slice derives, per position,
+//     B_p = the m-th smallest of the published entries [p] over the slices,  m = ceil(KPT / (p+1)):
+// m slices each hold p+1 rows at or below B_p, slices hold disjoint rows, so at least KPT >= K rows
+// lie at or below B_p and no row above it can be among the K best (rows EQUAL to it are kept).
+// Every position is valid on its own with one value per slice, read whenever (entries only ever
+// decrease; a stale value is a looser bound), so there is nothing to tear.  For 12 slices and
+// KPT = 10: p = 1 (the 5th smallest second-best) sits near the 17th best row overall, p = 0 near
+// the 21st, p = 9 (the old bound) near the 65th.  Exchanges follow a doubling schedule (stages 1,
+// 2, 4, ... 64, then every 64): the lists move fastest at the start.
+// Layout: gl[query][rank][slices padded to 4] ints, 0x7fffffff = nothing published.
+constexpr int kI8MaxRanks = 5;
+template <int KPT>
+GGNN_DEV constexpr int i8_rank_pos(int i)
+{
+  return KPT == 4    ? (i == 0 ? 0 : i == 1 ? 1 : 3)
+         : KPT == 10 ? (i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : i == 3 ? 4 : 9)
+                     : (i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 3 : i == 3 ? 7 : 15);
+}
+template <int KPT>
+GGNN_DEV constexpr int i8_ranks()
+{
+  return KPT == 4 ? 3 : 5;
+}
+// the M-th smallest of `n4` x 4 published values (unused slots hold 0x7fffffff)
+template <int M>
+GGNN_DEV int i8_mth_smallest(const int* col, int n4)
+{
+  int t[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k)
+    t[k] = 0x7fffffff;
+  // up to 32 slices in two rounds of 16: the loads of a round first (one round trip), device-
+  // coherent -- the values come from other XCDs; 16 registers, not 32: the kernel has none to spare
+  for (int b0 = 0; b0 < n4; b0 += 4) {
+    int v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      v[e] = (b0 * 4 + e < n4 * 4)
+                 ? __hip_atomic_load(col + b0 * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                 : 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int x = v[e];
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const int lo = min(t[k], x);
+        x = max(t[k], x);
+        t[k] = lo;
+      }
+    }
+  }
+  return t[M - 1];
+}
+
+// stages at which a slice exchanges: 1, 2, 4, ... while the lists still move fast, then every
+// kI8v2Refresh-th (an exchange is five dependent-free batches of device-coherent loads, ~1.5 stages)
+GGNN_DEV bool i8_exchange_stage(uint32_t st)
+{
+  if (st == 0)
+    return false;
+  return st < static_cast<uint32_t>(kI8v2Refresh) ? (st & (st - 1)) == 0 : st % kI8v2Refresh == 0;
+}
 
 GGNN_DEV int i8v2_qrow(int r, int h)
 {
@@ -112,11 +181,11 @@ __global__ void __launch_bounds__(256)
   const bool my_valid = my_q < a.Nq;
   const int qn_q = my_valid ? static_cast<int>(a.qnorm[my_q]) : 0;
   int Te = my_valid ? kTeInf : -kTeInf;  // candidates need d < Te
-  if (my_valid && a.gthr) {
-    const uint32_t g = a.gthr[my_q];
-    if (g < 0x7f800000u)
-      Te = min(Te, static_cast<int>(__uint_as_float(g)) + 1);
-  }
+  // this query's block of the exchange area: [rank][slices padded to 4]
+  const int sl4 = static_cast<int>((a.slices + 3) / 4);
+  int* gl_q = a.gthr ? reinterpret_cast<int*>(a.gthr) +
+                           static_cast<size_t>(my_valid ? my_q : 0) * kI8MaxRanks * 4 * sl4
+                     : nullptr;
   // the query's K-best set: SORTED ascending by (distance, index), unused slots hold "infinity"
   // (so the threshold is simply the last entry and filling needs no special case)
   int sd[KPT], si[KPT];
@@ -126,7 +195,6 @@ __global__ void __launch_bounds__(256)
     si[k] = 0x7fffffff;
   }
   int hq_used = 0;         // offset the accumulators of this query currently carry
-  int last_pub = 0x7fffffff;
   int Te_seen = 0x7fffffff;
   bool offsets_stale = false;  // wave-uniform
   qn_w[lane] = qn_q;
@@ -237,14 +305,24 @@ __global__ void __launch_bounds__(256)
   auto refresh = [&]() {
     if (__any(pc_w[lane] > 0))
       flush();
-    if (a.gthr && my_valid) {
-      if (sd[KPT - 1] < last_pub) {
-        atomicMin(a.gthr + my_q, __float_as_uint(static_cast<float>(sd[KPT - 1])));
-        last_pub = sd[KPT - 1];
-      }
-      const uint32_t g = __hip_atomic_load(a.gthr + my_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g < 0x7f800000u)
-        Te = min(Te, static_cast<int>(__uint_as_float(g)) + 1);
+    if (gl_q && my_valid) {
+      // publish this slice's entries (single writer per word), then derive the bounds
+      constexpr int NR = i8_ranks<KPT>();
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((((a.rank_mask >> I) & 1u)
+              ? __hip_atomic_store(gl_q + I * 4 * sl4 + blockIdx.y, sd[i8_rank_pos<KPT>(I)],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+              : (void)0),
+         ...);
+        int bound = 0x7fffffff;
+        ((bound = ((a.rank_mask >> I) & 1u)
+                      ? min(bound, i8_mth_smallest<(KPT + i8_rank_pos<KPT>(I)) / (i8_rank_pos<KPT>(I) + 1)>(
+                                       gl_q + I * 4 * sl4, sl4))
+                      : bound),
+         ...);
+        if (bound < 0x7fffffff)
+          Te = min(Te, bound + 1);
+      }(std::make_integer_sequence<int, NR>{});
       te_w[lane] = Te;
     }
     if (__any(Te != Te_seen))
@@ -365,7 +443,7 @@ __global__ void __launch_bounds__(256)
     // (the exchange first: it waits for its own atomic load with vmcnt(0), which must not have
     // this stage's freshly issued staging loads in front of it)
 #if !defined(GGNN_I8_EXP) || GGNN_I8_EXP != 2   // (2: timing experiment without the exchange)
-    if (st && st % kI8v2Refresh == 0) {
+    if (i8_exchange_stage(st)) {
       I8_T0();
       refresh();
       I8_T1(12);
@@ -456,7 +534,7 @@ __global__ void __launch_bounds__(256)
       const uint32_t row0 = begin + st * SR;
       const uint32_t buf = st & 1;
       const uint8_t* blk = lds_b + buf * stage_bytes;
-      if (st && st % kI8v2Refresh == 0)
+      if (i8_exchange_stage(st))
         refresh();
       if (st + 1 < nstages)
         stage_load(row0 + SR, sva, bna);  // written to the other buffer at the end of this stage
@@ -509,8 +587,6 @@ __global__ void __launch_bounds__(256)
   I8_STAT(11, clock64() - t_kernel0);
 #endif
   flush();
-  if (a.gthr && my_valid && sd[KPT - 1] < last_pub)
-    atomicMin(a.gthr + my_q, __float_as_uint(static_cast<float>(sd[KPT - 1])));
   if (a.part_ids && my_valid) {
     const size_t o = (static_cast<size_t>(blockIdx.y) * a.Nq + my_q) * KPT;
 #pragma unroll
@@ -541,8 +617,12 @@ size_t bf_i8v2_lds_bytes()
          (2 * kI8v2StageRows + 4 * 4 * 64 + 2 * 4 * kI8v2Pend * 64) * sizeof(int);
 }
 
-void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t warm_rows,
-                    hipStream_t stream)
+size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices)
+{
+  return static_cast<size_t>(Nq) * kI8MaxRanks * 4 * ((slices + 3) / 4);
+}
+
+void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipStream_t stream)
 {
   const size_t lds2 = bf_i8v2_lds_bytes();
   const uint32_t nm = (m.D + 31) / 32;
@@ -557,19 +637,8 @@ void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint
 #undef GGNN_I8V2
   GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds2)));
-  // seeding launch: the head of the base, all queries, no lists written -- every slice of the
-  // main launch then starts from the KP-th best of these rows instead of "everything passes"
-  const uint32_t warm = std::min(m.N_base, warm_rows / kBfTileRows * kBfTileRows);
-  if (warm >= 256 && slices > 1) {
-    BfMfmaArgs w = m;
-    w.part_ids = nullptr;
-    w.part_dists = nullptr;
-    w.N_base = warm;
-    w.rows_per_slice = warm;
-    w.slices = 1;
-    void* wargs[] = {&w};
-    GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, 1), dim3(256), wargs, lds2, stream));
-  }
+  // (rounds 3-4 had an optional seeding launch over the head of the base here: 40 workgroups,
+  // 1.1 ms serial, more than the cold starts it saved; removed with the multi-position exchange)
   BfMfmaArgs mm = m;
   void* kargs[] = {&mm};
   GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds2, stream));

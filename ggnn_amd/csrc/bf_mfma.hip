@@ -1256,7 +1256,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_parts = pad4(parts);
   const size_t n_rescan = pad4(rescan_entries);
   const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
-  const size_t n_gthr = use_i8v2 ? pad4(a.Nq) : 0;  // per-query bound shared by the slices
+  // exchange area of the i8 register-set kernel (bf_i8.hip "bound exchange")
+  const size_t n_gthr = use_i8v2 ? pad4(bf_i8v2_exchange_ints(a.Nq, slices)) : 0;
   // chunked float kernel: the query set once more, in operand order (QueryWindow)
   const uint32_t pack_chunks = (!use_i8 && a.D > 128) ? (a.D + 127) / 128 : 0;
   const size_t n_qpack = static_cast<size_t>(qblocks) * kBfQueriesPerBlock * pack_chunks * 128;
@@ -1277,8 +1278,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   uint32_t* gthr = reinterpret_cast<uint32_t*>(q_shifted + pad4(n_qshift));
   float* q_packed = reinterpret_cast<float*>(gthr + n_gthr);
   GGNN_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(uint32_t), stream));
-  if (use_i8v2)  // +inf
-    GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7f800000, a.Nq,
+  if (use_i8v2)  // "nothing published"
+    GGNN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(gthr), 0x7fffffff, n_gthr,
                                      stream));
   if (equal_ranges) {
     // not every query block has all `slices` parts: the others read as empty lists
@@ -1405,11 +1406,10 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   }
   if (use_i8v2) {
     m.gthr = hook(kHookBfI8NoShare) ? nullptr : gthr;  // (A/B hook)
-    // hook BF_I8_WARM = <rows>: seeding launch over the head of the base (tuning hook; off: a
-    // 40-workgroup launch costs more than the per-slice cold starts it saves)
-    const uint32_t warm = static_cast<uint32_t>(
-        std::clamp<int64_t>(hook(kHookBfI8Warm), 0, static_cast<int64_t>(a.N_base)));
-    launch_bf_i8v2(m, qblocks, slices, warm, stream);
+    // hook BF_I8_RANKS: bit mask of the published set positions the slices use (-1 = all; the
+    // highest bit of a set size alone = the single shared bound of rounds 3-4)
+    m.rank_mask = static_cast<uint32_t>(hook(kHookBfI8Ranks)) & 31u;
+    launch_bf_i8v2(m, qblocks, slices, stream);
   }
   else if (use_i8) {
     // (+ 128 words: bf_insert_hits reads up to 126 words past the last list unconditionally)

@@ -17,7 +17,7 @@ constexpr Entry kTable[kHookCount] = {
     {"PRESCREEN", 1},     {"EXCHANGE", 0},      {"SYM_PRESCREEN", -1}, {"SHARD_OVERLAP", 1},
     {"VIS_SLOTS", 8},     {"VIS_TAG_SET", 1}, {"QUERY_SPLIT", -1}, {"RESIDENT_SHARDS", 0}, {"XCD_MAP", 3}, {"BF_POOL_KEEP_MB", 1024}, {"BF_NO_I8", 0},
     {"BF_I8_V1", 0},      {"BF_SLICES", 0},     {"BF_NO_CENTER", 0},   {"BF_TILES", 3},
-    {"BF_I8_NOSHARE", 0}, {"BF_I8_WARM", 0},    {"BF_SCAN", 0},        {"RCCL_FAIL_AFTER", 0},
+    {"BF_I8_NOSHARE", 0}, {"BF_I8_RANKS", -1},    {"BF_SCAN", 0},        {"RCCL_FAIL_AFTER", 0},
     {"QUERY_EARLY", 1},   {"MERGE_EARLY", 1},   {"QUERY_LDS_PAD", 0},
     {"QUERY_GLOBAL_RING", 1},
 };

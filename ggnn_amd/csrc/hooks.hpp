@@ -26,7 +26,7 @@ enum Hook {
   kHookBfNoCenter,      // BF_NO_CENTER     1 = rows not shifted by the column mean
   kHookBfTiles,         // BF_TILES         2 | 4 base tiles per accumulator group (D > 128)
   kHookBfI8NoShare,     // BF_I8_NOSHARE    1 = slices do not share their bound
-  kHookBfI8Warm,        // BF_I8_WARM       rows of a seeding launch (0 = none)
+  kHookBfI8Ranks,       // BF_I8_RANKS      bit mask of the set positions the slices exchange (-1 = all)
   kHookBfScan,          // BF_SCAN          1 = scan kernels instead of the matrix-core path
   kHookRcclFailAfter,   // RCCL_FAIL_AFTER  fault injection: the n-th exchange (1-based) reports an
                         //                  RCCL failure (0 = never); exercises the peer-copy fallback
