@@ -25,6 +25,7 @@ struct BfMfmaArgs {
   uint32_t* gthr;  // i8 v2 kernel: exchange area of the slices' published set entries
                    // ([Nq][5 ranks][slices padded to 4] ints, 0x7fffffff = none), or null
   uint32_t rank_mask;  // which of the published positions are used (bit i = rank i)
+  uint32_t refresh_every;  // stages between exchanges after the doubling phase
   // float tile kernels, equal_ranges != 0: the (query block, unit) sequence is cut into equal
   // ranges, a unit being 32 rows (single chunk) or one accumulator group of T x 32 rows (chunked)
   uint32_t equal_ranges;
@@ -42,5 +43,6 @@ constexpr uint32_t kBfI8RowStride = 144;
 void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipStream_t stream);
 size_t bf_i8v2_lds_bytes();
 size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices);
+uint32_t bf_i8v2_default_rank_mask(uint32_t KP, uint32_t slices);
 
 }  // namespace ggnn_amd

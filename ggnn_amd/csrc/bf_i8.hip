@@ -83,7 +83,7 @@ __device__ unsigned long long g_i8_stats[16];
 // Layout: gl[query][rank][slices padded to 4] ints, 0x7fffffff = nothing published.
 constexpr int kI8MaxRanks = 5;
 template <int KPT>
-GGNN_DEV constexpr int i8_rank_pos(int i)
+__host__ __device__ constexpr int i8_rank_pos(int i)
 {
   return KPT == 4    ? (i == 0 ? 0 : i == 1 ? 1 : 3)
          : KPT == 10 ? (i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : i == 3 ? 4 : 9)
@@ -127,11 +127,11 @@ GGNN_DEV int i8_mth_smallest(const int* col, int n4)
 
 // stages at which a slice exchanges: 1, 2, 4, ... while the lists still move fast, then every
 // kI8v2Refresh-th (an exchange is five dependent-free batches of device-coherent loads, ~1.5 stages)
-GGNN_DEV bool i8_exchange_stage(uint32_t st)
+GGNN_DEV bool i8_exchange_stage(uint32_t st, uint32_t every)
 {
   if (st == 0)
     return false;
-  return st < static_cast<uint32_t>(kI8v2Refresh) ? (st & (st - 1)) == 0 : st % kI8v2Refresh == 0;
+  return st < every ? (st & (st - 1)) == 0 : st % every == 0;
 }
 
 GGNN_DEV int i8v2_qrow(int r, int h)
@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(256)
   int* gl_q = a.gthr ? reinterpret_cast<int*>(a.gthr) +
                            static_cast<size_t>(my_valid ? my_q : 0) * kI8MaxRanks * 4 * sl4
                      : nullptr;
+  const bool gl_q_any = a.gthr != nullptr && a.rank_mask != 0;  // uniform: anything to exchange
   // the query's K-best set: SORTED ascending by (distance, index), unused slots hold "infinity"
   // (so the threshold is simply the last entry and filling needs no special case)
   int sd[KPT], si[KPT];
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(256)
     // (the exchange first: it waits for its own atomic load with vmcnt(0), which must not have
     // this stage's freshly issued staging loads in front of it)
 #if !defined(GGNN_I8_EXP) || GGNN_I8_EXP != 2   // (2: timing experiment without the exchange)
-    if (i8_exchange_stage(st)) {
+    if (gl_q_any && i8_exchange_stage(st, a.refresh_every)) {
       I8_T0();
       refresh();
       I8_T1(12);
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(256)
       const uint32_t row0 = begin + st * SR;
       const uint32_t buf = st & 1;
       const uint8_t* blk = lds_b + buf * stage_bytes;
-      if (i8_exchange_stage(st))
+      if (gl_q_any && i8_exchange_stage(st, a.refresh_every))
         refresh();
       if (st + 1 < nstages)
         stage_load(row0 + SR, sva, bna);  // written to the other buffer at the end of this stage
@@ -615,6 +616,20 @@ size_t bf_i8v2_lds_bytes()
 {
   return 2 * kI8v2StageRows * kBfI8RowStride +
          (2 * kI8v2StageRows + 4 * 4 * 64 + 2 * 4 * kI8v2Pend * 64) * sizeof(int);
+}
+
+uint32_t bf_i8v2_default_rank_mask(uint32_t KP, uint32_t slices)
+{
+  const int n = KP == 4 ? 3 : 5;
+  for (int i = 0; i < n; ++i) {
+    const uint32_t p = KP == 4    ? static_cast<uint32_t>(i8_rank_pos<4>(i))
+                       : KP == 10 ? static_cast<uint32_t>(i8_rank_pos<10>(i))
+                                  : static_cast<uint32_t>(i8_rank_pos<16>(i));
+    const uint32_t need = (KP + p) / (p + 1);
+    if (2 * need <= slices || i == n - 1)
+      return 1u << i;
+  }
+  return 0;
 }
 
 size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices)

@@ -1408,7 +1408,18 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     m.gthr = hook(kHookBfI8NoShare) ? nullptr : gthr;  // (A/B hook)
     // hook BF_I8_RANKS: bit mask of the published set positions the slices use (-1 = all; the
     // highest bit of a set size alone = the single shared bound of rounds 3-4)
-    m.rank_mask = static_cast<uint32_t>(hook(kHookBfI8Ranks)) & 31u;
+    // default: ONE position -- an exchange costs ~0.2 ms per position and launch (measured: all
+    // five 3.08 ms, the last entry alone 3.01, position 1 alone 2.28 for 10k x 1M x 128, k = 10) --
+    // the lowest one that at most half of the slices have to reach (12 slices, sets of 10: position
+    // 1, the 5th smallest second-best entry; 32 slices: position 0; 4 slices: position 4)
+    const int64_t hr = hook(kHookBfI8Ranks);
+    if (hr >= 0)
+      m.rank_mask = static_cast<uint32_t>(hr) & 31u;
+    else
+      m.rank_mask = bf_i8v2_default_rank_mask(KP, slices);
+    if (slices <= 1)
+      m.rank_mask = 0;  // nothing to exchange
+    m.refresh_every = static_cast<uint32_t>(std::clamp<int64_t>(hook(kHookBfI8Refresh), 1, 1 << 20));
     launch_bf_i8v2(m, qblocks, slices, stream);
   }
   else if (use_i8) {

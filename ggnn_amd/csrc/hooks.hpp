@@ -35,6 +35,7 @@ enum Hook {
   kHookMergeEarly,      // MERGE_EARLY      the same switch for the merge kernel
   kHookQueryLdsPad,     // QUERY_LDS_PAD    extra bytes of LDS per wave of the early-rows query kernels
   kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = early-rows kernels keep a visited ring in LDS even when it cannot wrap
+  kHookBfI8Refresh,     // BF_I8_REFRESH    stages between bound exchanges of the i8 kernel's slices
   kHookCount
 };
 

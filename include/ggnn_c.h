@@ -244,7 +244,10 @@ void ggnn_set_log_level(int level);
  *   BF_I8_NOSHARE       0     1 = slices of the i8 kernel do not share their bound
  *   BF_I8_RANKS        -1     bit mask of the K-best set positions the slices of the i8 kernel
  *                             exchange (bit i = the i-th of {0,1,2,4,9} for sets of 10); -1 = all,
- *                             16 = only the last entry (the single shared bound of rounds 3-4)
+ *                             16 = only the last entry (the single shared bound of rounds 3-4);
+ *                             default: one position chosen from the number of slices
+ *   BF_I8_REFRESH      64     stages of 128 rows between those exchanges (before that: at stages
+ *                             1, 2, 4, ...)
  *   BF_SCAN             0     1 = scan kernels instead of the matrix-core brute force
  *   RCCL_FAIL_AFTER     0     fault injection: the n-th multi-GPU exchange of the process reports an
  *                             RCCL failure (exercises the peer-copy fallback); 0 = never
