@@ -26,6 +26,8 @@ struct BfMfmaArgs {
                    // ([Nq][5 ranks][slices padded to 4] ints, 0x7fffffff = none), or null
   uint32_t rank_mask;  // which of the published positions are used (bit i = rank i)
   uint32_t refresh_every;  // stages between exchanges after the doubling phase
+  int32_t* seed;       // [Nq] K-th best distance over the head of the base (seeding launch), or null
+  uint32_t seeding;    // this launch IS the seeding launch: writes `seed`, no lists
   // float tile kernels, equal_ranges != 0: the (query block, unit) sequence is cut into equal
   // ranges, a unit being 32 rows (single chunk) or one accumulator group of T x 32 rows (chunked)
   uint32_t equal_ranges;
@@ -38,9 +40,11 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kBfI8RowStride = 144;
 
-// bf_i8.hip: launches bf_i8v2_kernel for KP in {4, 10, 16}; m.gthr must point to
-// bf_i8v2_exchange_ints(Nq, slices) words initialised to 0x7fffffff (or be null: no exchange)
-void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipStream_t stream);
+// bf_i8.hip: launches bf_i8v2_kernel for KP in {4, 10, 16} (a seeding launch over the first
+// seed_rows rows of the base first, when m.seed is set and there are several slices); m.gthr must
+// point to bf_i8v2_exchange_ints(Nq, slices) words initialised to 0x7fffffff (or be null: no exchange)
+void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t seed_rows,
+                    hipStream_t stream);
 size_t bf_i8v2_lds_bytes();
 size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices);
 uint32_t bf_i8v2_default_rank_mask(uint32_t KP, uint32_t slices);

@@ -187,6 +187,15 @@ __global__ void __launch_bounds__(256)
                            static_cast<size_t>(my_valid ? my_q : 0) * kI8MaxRanks * 4 * sl4
                      : nullptr;
   const bool gl_q_any = a.gthr != nullptr && a.rank_mask != 0;  // uniform: anything to exchange
+  // seeded start: every slice begins with the K-th best distance over the head of the base (one
+  // short launch, all queries) instead of "everything passes" -- the cold start of a slice is
+  // K (1 + ln(128 / K)) ~ 35 insertions per query in its first stage alone, three quarters of all
+  // hits once the slices exchange bounds
+  if (my_valid && a.seed && !a.seeding) {
+    const int g = a.seed[my_q];
+    if (g < 0x7fffffff)
+      Te = min(Te, g + 1);
+  }
   // the query's K-best set: SORTED ascending by (distance, index), unused slots hold "infinity"
   // (so the threshold is simply the last entry and filling needs no special case)
   int sd[KPT], si[KPT];
@@ -588,6 +597,8 @@ __global__ void __launch_bounds__(256)
   I8_STAT(11, clock64() - t_kernel0);
 #endif
   flush();
+  if (a.seeding && a.seed && my_valid)
+    a.seed[my_q] = sd[KPT - 1];
   if (a.part_ids && my_valid) {
     const size_t o = (static_cast<size_t>(blockIdx.y) * a.Nq + my_q) * KPT;
 #pragma unroll
@@ -637,7 +648,8 @@ size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices)
   return static_cast<size_t>(Nq) * kI8MaxRanks * 4 * ((slices + 3) / 4);
 }
 
-void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipStream_t stream)
+void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t seed_rows,
+                    hipStream_t stream)
 {
   const size_t lds2 = bf_i8v2_lds_bytes();
   const uint32_t nm = (m.D + 31) / 32;
@@ -652,9 +664,29 @@ void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, hipS
 #undef GGNN_I8V2
   GGNN_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds2)));
-  // (rounds 3-4 had an optional seeding launch over the head of the base here: 40 workgroups,
-  // 1.1 ms serial, more than the cold starts it saved; removed with the multi-position exchange)
+  // seeding launch: the first seed_rows rows, all queries, one workgroup per query block, no lists
+  // written -- its K-th best distance is every slice's first bound.  (Rounds 3-4 tried this with
+  // tens of thousands of rows: 1.1 ms of a 40-workgroup launch, more than it saved.  A few hundred
+  // rows are enough -- the first exchange between the slices takes over after 128 rows -- and
+  // cost ~20 us.)
+  const uint32_t seed = std::min(m.N_base, seed_rows / kI8v2StageRows * kI8v2StageRows);
+  if (m.seed && seed >= static_cast<uint32_t>(kI8v2StageRows) && slices > 1) {
+    BfMfmaArgs w = m;
+    w.part_ids = nullptr;
+    w.part_dists = nullptr;
+    w.N_base = seed;
+    w.rows_per_slice = seed;
+    w.slices = 1;
+    w.gthr = nullptr;
+    w.rank_mask = 0;
+    w.seeding = 1;
+    void* wargs[] = {&w};
+    GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, 1), dim3(256), wargs, lds2, stream));
+  }
   BfMfmaArgs mm = m;
+  mm.seeding = 0;
+  if (!(m.seed && seed >= static_cast<uint32_t>(kI8v2StageRows) && slices > 1))
+    mm.seed = nullptr;
   void* kargs[] = {&mm};
   GGNN_HIP_CHECK(hipLaunchKernel(kern, dim3(qblocks, slices), dim3(256), kargs, lds2, stream));
 }

@@ -1257,7 +1257,7 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   const size_t n_rescan = pad4(rescan_entries);
   const size_t n_qshift = center ? static_cast<size_t>(a.Nq) * a.D : 0;  // shifted query copy
   // exchange area of the i8 register-set kernel (bf_i8.hip "bound exchange")
-  const size_t n_gthr = use_i8v2 ? pad4(bf_i8v2_exchange_ints(a.Nq, slices)) : 0;
+  const size_t n_gthr = use_i8v2 ? pad4(bf_i8v2_exchange_ints(a.Nq, slices)) + pad4(a.Nq) : 0;
   // chunked float kernel: the query set once more, in operand order (QueryWindow)
   const uint32_t pack_chunks = (!use_i8 && a.D > 128) ? (a.D + 127) / 128 : 0;
   const size_t n_qpack = static_cast<size_t>(qblocks) * kBfQueriesPerBlock * pack_chunks * 128;
@@ -1420,7 +1420,12 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
     if (slices <= 1)
       m.rank_mask = 0;  // nothing to exchange
     m.refresh_every = static_cast<uint32_t>(std::clamp<int64_t>(hook(kHookBfI8Refresh), 1, 1 << 20));
-    launch_bf_i8v2(m, qblocks, slices, stream);
+    // seeds behind the exchange area (both initialised to "nothing" above); hook BF_I8_SEED: rows
+    // of the seeding launch (0 = none)
+    m.seed = reinterpret_cast<int32_t*>(gthr) + pad4(bf_i8v2_exchange_ints(a.Nq, slices));
+    const uint32_t seed_rows = static_cast<uint32_t>(
+        std::clamp<int64_t>(hook(kHookBfI8Seed), 0, static_cast<int64_t>(a.N_base)));
+    launch_bf_i8v2(m, qblocks, slices, seed_rows, stream);
   }
   else if (use_i8) {
     // (+ 128 words: bf_insert_hits reads up to 126 words past the last list unconditionally)

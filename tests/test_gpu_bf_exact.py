@@ -286,7 +286,9 @@ def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
                 {"GGNN_BF_SLICES": "1"}, {"GGNN_BF_I8_V1": "1"}, {"GGNN_BF_SLICES": "2"},
                 {"GGNN_BF_SLICES": "5", "GGNN_BF_I8_RANKS": "3"}, {"GGNN_BF_SLICES": "32"},
                 {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_RANKS": "2"},
-                {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_NOSHARE": "1"}):
+                {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_NOSHARE": "1"},
+                {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_SEED": "0"},
+                {"GGNN_BF_SLICES": "9", "GGNN_BF_I8_SEED": "4096", "GGNN_BF_I8_REFRESH": "2"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         ids, d = ops.bf_query(d_base, d_q, K)
