@@ -80,7 +80,7 @@ __device__ unsigned long long g_i8_stats[16];
 // KPT = 10: p = 1 (the 5th smallest second-best) sits near the 17th best row overall, p = 0 near
 // the 21st, p = 9 (the old bound) near the 65th.  Exchanges follow a doubling schedule (stages 1,
 // 2, 4, ... 64, then every 64): the lists move fastest at the start.
-// Layout: gl[query][rank][slices padded to 4] ints, 0x7fffffff = nothing published.
+// Layout: gl[query][rank][slices padded to 16] ints, 0x7fffffff = nothing published.
 constexpr int kI8MaxRanks = 5;
 template <int KPT>
 __host__ __device__ constexpr int i8_rank_pos(int i)
@@ -102,15 +102,26 @@ GGNN_DEV int i8_mth_smallest(const int* col, int n4)
 #pragma unroll
   for (int k = 0; k < M; ++k)
     t[k] = 0x7fffffff;
-  // up to 32 slices in two rounds of 16: the loads of a round first (one round trip), device-
-  // coherent -- the values come from other XCDs; 16 registers, not 32: the kernel has none to spare
+  // up to 32 slices in two rounds of 16 (16 registers, not 32: the kernel has none to spare).
+  // The four 16-byte loads of a round are issued back to back and waited for ONCE, device-
+  // coherent (sc1: the values come from other XCDs).  As sixteen relaxed agent-scope atomic loads
+  // -- the first version -- the compiler waited for each one separately: ~17 us per exchange, 12 %
+  // of the kernel (stats build), where one round trip is ~1-2 us.  Slots past the slices were
+  // initialised to 0x7fffffff by the host (the area is padded to 16 per position).
   for (int b0 = 0; b0 < n4; b0 += 4) {
-    int v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      v[e] = (b0 * 4 + e < n4 * 4)
-                 ? __hip_atomic_load(col + b0 * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                 : 0x7fffffff;
+    i32x4 w0, w1, w2, w3;
+    const int* p = col + b0 * 4;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+        : "v"(p)
+        : "memory");
+    const int v[16] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3],
+                       w2[0], w2[1], w2[2], w2[3], w3[0], w3[1], w3[2], w3[3]};
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       int x = v[e];
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(256)
   const int qn_q = my_valid ? static_cast<int>(a.qnorm[my_q]) : 0;
   int Te = my_valid ? kTeInf : -kTeInf;  // candidates need d < Te
   // this query's block of the exchange area: [rank][slices padded to 4]
-  const int sl4 = static_cast<int>((a.slices + 3) / 4);
+  const int sl4 = static_cast<int>((a.slices + 15) / 16 * 4);  // int4 groups per position (padded to 16 slices)
   int* gl_q = a.gthr ? reinterpret_cast<int*>(a.gthr) +
                            static_cast<size_t>(my_valid ? my_q : 0) * kI8MaxRanks * 4 * sl4
                      : nullptr;
@@ -645,7 +656,7 @@ uint32_t bf_i8v2_default_rank_mask(uint32_t KP, uint32_t slices)
 
 size_t bf_i8v2_exchange_ints(uint32_t Nq, uint32_t slices)
 {
-  return static_cast<size_t>(Nq) * kI8MaxRanks * 4 * ((slices + 3) / 4);
+  return static_cast<size_t>(Nq) * kI8MaxRanks * 16 * ((slices + 15) / 16);
 }
 
 void launch_bf_i8v2(const BfMfmaArgs& m, uint32_t qblocks, uint32_t slices, uint32_t seed_rows,

@@ -248,8 +248,9 @@ void ggnn_set_log_level(int level);
  *                             default: one position chosen from the number of slices
  *   BF_I8_REFRESH      64     stages of 128 rows between those exchanges (before that: at stages
  *                             1, 2, 4, ...)
- *   BF_I8_SEED        512     rows of the i8 kernel's seeding launch (the K-th best distance over
- *                             the head of the base is every slice's first bound); 0 = none
+ *   BF_I8_SEED          0     rows of an optional seeding launch of the i8 kernel (the K-th best
+ *                             distance over the head of the base as every slice's first bound);
+ *                             0 = none (measured: the launch costs what its fewer hits save)
  *   BF_SCAN             0     1 = scan kernels instead of the matrix-core brute force
  *   RCCL_FAIL_AFTER     0     fault injection: the n-th multi-GPU exchange of the process reports an
  *                             RCCL failure (exercises the peer-copy fallback); 0 = never
