@@ -441,6 +441,28 @@ struct ggnn_handle {
   ggnn_location base_loc{GGNN_CPU};
   int base_gpu{0};
   std::vector<uint8_t> base_host_copy;
+  bool base_host_copy_registered{false};  // page-locked (hipHostRegister) while shards swap
+  // out-of-core shards re-read their rows at every swap on a copy stream: from pageable memory
+  // that copy is staged and synchronous, i.e. it does not overlap the search (round-4 advisor
+  // finding) -- the engine's own host copy is page-locked for as long as it is swapped from
+  void pin_host_copy()
+  {
+    if (base_host_copy_registered || base_host_copy.empty())
+      return;
+    if (hipHostRegister(base_host_copy.data(), base_host_copy.size(), hipHostRegisterDefault) ==
+        hipSuccess)
+      base_host_copy_registered = true;
+    else
+      (void)hipGetLastError();  // (still correct from pageable memory, only not overlapped)
+  }
+  void drop_host_copy()
+  {
+    if (base_host_copy_registered)
+      (void)hipHostUnregister(base_host_copy.data());
+    base_host_copy_registered = false;
+    base_host_copy.clear();
+    base_host_copy.shrink_to_fit();
+  }
   DeviceBuffer base_dev_copy;
   uint64_t base_N{0};
   uint32_t base_D{0};  // dimension as given by the caller
@@ -471,7 +493,12 @@ struct ggnn_handle {
   const char* last_exchange{"none"};
   uint32_t last_query_parts{1};  // half-batches the last blocking query was searched in
 
-  ~ggnn_handle() { destroy_comms(); }
+  ~ggnn_handle()
+  {
+    destroy_comms();
+    if (base_host_copy_registered)
+      (void)hipHostUnregister(base_host_copy.data());
+  }
   void destroy_comms()
   {
     if (!comms.empty() && Rccl::get().ok)
@@ -642,9 +669,14 @@ struct ggnn_handle {
     (void)ctx;
     if (resident_need <= free_b)
       return 0;
-    GGNN_REQUIRE(free_b > scratch_b + pool_b + base_b, GGNN_OUT_OF_MEMORY,
+    // out of core: the slots must leave room for what is allocated later -- query staging and
+    // result buffers, the packed exchange blocks, the scratch pool of the brute force and of long
+    // searches (round-4 advisor finding: the slots took everything but the build scratch)
+    const size_t headroom = std::min<size_t>(free_b / 8, size_t{2} << 30);
+    GGNN_REQUIRE(free_b > scratch_b + headroom + pool_b + base_b, GGNN_OUT_OF_MEMORY,
                  "GPU memory does not suffice for a single shard. use smaller shards.");
-    return static_cast<uint32_t>(std::min<size_t>(spg - 1, (free_b - scratch_b) / (pool_b + base_b)));
+    return static_cast<uint32_t>(
+        std::min<size_t>(spg - 1, (free_b - scratch_b - headroom) / (pool_b + base_b)));
   }
 
   void setup_swap(DeviceCtx& ctx, uint32_t slots, bool base_on_this_gpu)
@@ -653,6 +685,8 @@ struct ggnn_handle {
     sw->device = ctx.device;
     sw->slots = slots;
     sw->base_borrowed = base_on_this_gpu;
+    if (!base_on_this_gpu && base_loc == GGNN_CPU && base_src == base_host_copy.data())
+      pin_host_copy();
     const size_t pool_b = align8(Shard::pool_bytes(cfg));
     // host buffers first (fail early, as the reference does): ggnn_set_cpu_memory_limit bounds them
     const size_t host_n = std::max<size_t>(
@@ -768,8 +802,7 @@ struct ggnn_handle {
     sw.host_shard[h] = static_cast<int>(si);
     sw.on_disk[si] = 0;
     if (sw.host.size() < shards_per_gpu) {
-      if (graph_dir.empty())
-        graph_dir = std::filesystem::current_path();
+      // (graph_dir was resolved in prepare(): this runs on one host thread per GPU)
       write_part(ctx.first_shard + si, sw.host[h].p);
       sw.on_disk[si] = 1;
     }
@@ -798,6 +831,11 @@ struct ggnn_handle {
   // GGNNImpl::prepare, ggnn.cu:154-203
   void prepare(uint32_t KBuild)
   {
+    // the part files of out-of-core shards are written by one host thread per GPU: the directory
+    // is fixed here, before any of them runs (round-4 advisor finding: it was assigned lazily,
+    // unlocked, from those threads)
+    if (graph_dir.empty())
+      graph_dir = std::filesystem::current_path();
     GGNN_REQUIRE(!prepared, GGNN_INVALID_STATE, "A graph has already been built or loaded.");
     GGNN_REQUIRE(base_set, GGNN_INVALID_STATE,
                  "The base needs to be set before building a graph.");
@@ -1104,8 +1142,7 @@ struct ggnn_handle {
     bool borrowed_from_copy = false;
     for (const DeviceCtx& ctx : devs)
       borrowed_from_copy |= (ctx.base_copy.p == nullptr);
-    base_host_copy.clear();
-    base_host_copy.shrink_to_fit();
+    drop_host_copy();
     if (!borrowed_from_copy)
       base_dev_copy.release();
   }
@@ -2030,7 +2067,17 @@ ggnn_status ggnn_set_working_directory(ggnn_t* h, const char* dir)
   return guarded(h, [&] {
     // ggnn.cu:69-76
     const std::filesystem::path p = dir ? dir : "";
-    h->graph_dir = p.empty() ? std::filesystem::current_path() : std::filesystem::absolute(p);
+    const auto target = p.empty() ? std::filesystem::current_path() : std::filesystem::absolute(p);
+    // graph parts of out-of-core shards live in the directory they were written to: store() skips
+    // them as "already on disk" and read_part() would look for them in the new place
+    if (target != h->graph_dir)
+      for (const auto& ctx : h->devs)
+        if (ctx.swap)
+          for (const uint8_t on_disk : ctx.swap->on_disk)
+            GGNN_REQUIRE(!on_disk, GGNN_INVALID_STATE,
+                         "the working directory cannot change while graph parts of out-of-core "
+                         "shards live in " + h->graph_dir.string());
+    h->graph_dir = target;
     std::error_code ec;
     std::filesystem::create_directories(h->graph_dir, ec);
     GGNN_REQUIRE(!ec, GGNN_IO_ERROR, "cannot create working directory " + h->graph_dir.string());
@@ -2180,7 +2227,7 @@ ggnn_status ggnn_set_base(ggnn_t* h, const void* data, uint64_t N, uint32_t D, g
                  "base has already been set with a different data type");
     GGNN_REQUIRE(data != nullptr && N > 0 && D > 0, GGNN_INVALID_ARGUMENT, "empty base");
     const size_t bytes = N * D * dtype_size(dtype);
-    h->base_host_copy.clear();
+    h->drop_host_copy();
     h->base_dev_copy.release();
     h->devs.clear();  // a base staged for an earlier bf_query() is stale now
     h->base_src = data;
