@@ -45,13 +45,10 @@ constexpr int kI8v2StageRows = 128;  // four 32-row tiles per barrier
 #ifndef GGNN_I8_PEND
 #define GGNN_I8_PEND 8
 #endif
-#ifndef GGNN_I8_REFRESH
-#define GGNN_I8_REFRESH 64
-#endif
 constexpr int kI8v2Pend = GGNN_I8_PEND;         // pending candidates per query before a batch update
-constexpr int kI8v2Refresh = GGNN_I8_REFRESH;   // stages between exchanges once past the doubling phase
-                                                 // (single bound, rounds 3-4: every 2 stages 3.82 ms,
-                                                 //  4: 3.54, 8-16: 3.42, 64: 3.50)
+// (stages between bound exchanges once past the doubling phase: BfMfmaArgs::refresh_every, hook
+//  BF_I8_REFRESH, default 64.  With the single shared bound of rounds 3-4: every 2 stages 3.82 ms,
+//  4: 3.54, 8-16: 3.42, 64: 3.50.)
 constexpr int kTeInf = 1 << 30;
 
 #ifdef GGNN_I8_STATS

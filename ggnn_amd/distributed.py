@@ -134,7 +134,7 @@ class ShardedGGNN:
 
     def _can_split(self, t):
         """the preconditions of the engine's asynchronous lanes, as the C-level split checks them
-        (engine.cpp query_split): the query on the GPU, rows that need no padding (16-byte
+        (engine_query.cpp query_split): the query on the GPU, rows that need no padding (16-byte
         multiples), work counters off (they belong to one blocking launch) -- anything else keeps
         the single blocking engine.query(), which accepts all of it"""
         if not hasattr(self.engine, "query_async"):

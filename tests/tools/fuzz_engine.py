@@ -30,7 +30,7 @@ for case in range(n_cases):
     iters = int(rng.choice([50, 200, 256, 400, 600, 800, 1200, 2000]))  # > 480: tag set (traversal.hpp)
     pre = bool(rng.integers(0, 2))
     shards = int(rng.choice([1, 1, 2, 3, 4]))
-    # out-of-core: fewer GPU slots than shards (engine.cpp SwapState); 0 = all resident
+    # out-of-core: fewer GPU slots than shards (engine_swap.cpp, SwapState); 0 = all resident
     slots = int(rng.choice([0, 0, 1, 2])) if shards > 1 else 0
     slots = slots if slots < shards else 0
     tag_set = int(rng.integers(0, 4) > 0)  # mostly on (the default), sometimes the ring scan
