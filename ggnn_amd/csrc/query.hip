@@ -57,13 +57,15 @@ query_kernel(const QueryArgs a)
   // registers are needed while the requested code rows are live across the membership test)
   using DE = DistEngine<BaseT, LPR, NCH, EARLY && PSC::enabled>;
   DE de;
-  de.template load_query<MODE>(base, a.D, query + static_cast<size_t>(n) * a.D,
-                               lds_raw + wave_lds_ints((is_tag_set(HB) || GR) ? a.sorted : a.cache, HB));
+  de.template load_query<MODE>(
+      base, a.D, query + static_cast<size_t>(n) * a.D,
+      lds_raw + (is_tag_set(HB) ? tag_set_lds_ints(a.sorted, static_cast<uint32_t>(-HB))
+                                : wave_lds_ints(GR ? a.sorted : a.cache, HB)));
   PSC ps;
   load_prescreen(ps, a, query + static_cast<size_t>(n) * a.D);
 
   SortedList<R, HB, GR> sl;
-  if constexpr (GR)
+  if constexpr (GR && !is_tag_set(HB))
     sl.init_global_ring(a.KQuery, a.sorted, a.cache, xi, lds.known, static_cast<int>(a.vis_slots),
                         a.ring + static_cast<size_t>(n) * (a.cache - a.sorted));
   else if constexpr (is_tag_set(HB))
@@ -284,9 +286,24 @@ static void launch_query_r(const QueryArgs& args, uint32_t sorted, hipStream_t s
   // early rows (traversal.hpp): graph rows of <= 24 neighbours, first row read 8 lanes x 16 bytes
   // (hook QUERY_EARLY = 0: the round-1..4 order, A/B and test hook)
   if constexpr (early_rows_layout<LPR, NCH, PSC>()) {
-    // (not with the tag set of long rings: its state next to the requested rows spills 4-16
-    // registers, and a scratch reload waits for vmcnt(0), i.e. for the rows just requested)
+    // the tag set of long rings (513..2016 iterations): early rows only when the search cannot
+    // wrap its ring -- then the set is ring-less too (no store per pop: a store in flight turns
+    // every wait for the requested rows into vmcnt(0)); otherwise the round-4 order below
     const bool tagged = hb == 0 && fits && args.ring && (args.tag_bits == 8 || args.tag_bits == 9);
+    const bool tagged_ringless = tagged && args.max_iters <= args.cache - sorted &&
+                                 hook(kHookQueryGlobalRing) != 0;
+    if (args.KBuild <= 8 * kEarlySteps && sorted <= 64 && tagged_ringless &&
+        hook(kHookQueryEarly) != 0) {
+      const size_t tag_lds = tag_set_lds_bytes(sorted, args.cache - sorted) +
+                             DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes;
+      if (args.tag_bits == 8)
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -8, true, true>),
+                           grid_for(args.Nq), dim3(kWave), tag_lds, stream, args);
+      else
+        hipLaunchKernelGGL((query_kernel<BaseT, LPR, NCH, 1, MODE, PSC, -9, true, true>),
+                           grid_for(args.Nq), dim3(kWave), tag_lds, stream, args);
+      return;
+    }
     if (args.KBuild <= 8 * kEarlySteps && sorted <= 64 && !tagged && hook(kHookQueryEarly) != 0) {
       // (hook QUERY_LDS_PAD: extra bytes of LDS per wave -- occupancy experiments without a rebuild)
       const size_t qrow = DistEngine<BaseT, LPR, NCH, PSC::enabled>::kQueryLdsBytes +

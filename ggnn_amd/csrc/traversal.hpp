@@ -227,10 +227,14 @@ inline bool tag_set_usable(uint32_t vis, uint32_t n_base)
   return m >= 32 || (static_cast<uint64_t>(n_base) <= (1ull << m));
 }
 // LDS of one wave: known[sorted] | candidate scratch | tags | counts | stash
+__host__ __device__ inline size_t tag_set_lds_ints(uint32_t sorted, uint32_t nb_bits)
+{
+  const size_t nb = size_t{1} << nb_bits;
+  return sorted + WaveLds::extra_ints + kVisStash + (nb * 16 + nb) / 4;
+}
 inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
 {
-  const size_t nb = size_t{1} << tag_set_bucket_bits(vis);
-  return (sorted + WaveLds::extra_ints + kVisStash) * sizeof(int) + nb * 16 + nb;
+  return tag_set_lds_ints(sorted, tag_set_bucket_bits(vis)) * sizeof(int);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,9 +267,11 @@ inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
 // vmcnt(0) and also waited for the speculative graph row issued after them.)
 template <int R, int HB = 0, bool GR = false>
 struct SortedList {
-  static_assert(!GR || HB > 0, "global ring: only next to the hashed set");
+  static_assert(!GR || HB != 0, "ring-less: only with a hashed set or a tag set");
   static constexpr int kHashRegs = HB;
-  static constexpr bool kGlobalRing = is_tag_set(HB);
+  // (the tag set of long rings keeps its ring in global memory unless the search cannot wrap it:
+  // then it is ring-less as well, GR, with the same overflow list)
+  static constexpr bool kGlobalRing = is_tag_set(HB) && !GR;
   int ovf_n;                  // GR: keys in the overflow list (global memory)
   static constexpr int NB = 64 * HB;
   int key[R];
@@ -340,6 +346,7 @@ struct SortedList {
   {
     vis_head = 0;
     vis_count = 0;
+    ovf_n = 0;
     if constexpr (kTag) {
       // counts to zero; tags need no clearing (masked by the counts), the global ring is only
       // ever read below vis_count
@@ -350,7 +357,6 @@ struct SortedList {
       scan_mode = 0;
       return;
     }
-    ovf_n = 0;
     if constexpr (!GR) {
       for (int i = SORTED + threadIdx.x; i < SORTED + VIS; i += kWave)
         known[i] = kEmptyKey;
@@ -485,6 +491,11 @@ struct SortedList {
       if (threadIdx.x == 0)
         hstash[stash_n] = k;
       ++stash_n;
+    }
+    else if constexpr (GR) {
+      if (threadIdx.x == 0)
+        ring_g[ovf_n] = k;  // overflow list (at most one entry per pop, pops <= ring length)
+      ++ovf_n;
     }
     else
       scan_mode = 1;
@@ -646,9 +657,11 @@ struct SortedList {
         vis_insert(k0);
       }
     }
-    if constexpr (GR)
+    if constexpr (GR && !kTag)
       vis_insert(k0);  // (no wrap: pops <= max_iterations <= ring length)
-    if constexpr (kTag) {
+    if constexpr (GR && kTag)
+      tag_insert(k0);
+    if constexpr (kTag && !GR) {
       if (vis_count == VIS)
         scan_mode = 1;  // the ring wraps (tags are never removed): the ring scan takes over
       if (!scan_mode)
@@ -799,7 +812,7 @@ struct SortedList {
             acc1 = min(acc1, static_cast<unsigned>(hstash[t]) ^ c);
         }
       }
-      else
+      else if constexpr (!GR)
         acc1 = scan_global_ring(acc1, c, h, vis_count);
     }
     if constexpr (GR) {

@@ -16,6 +16,9 @@ from ggnn_amd import _lib
 ggnn.set_log_level(-1)
 n, d, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 rest = sys.argv[4:]
+base_kind = "lowrank16"   # --kind lowrank24: a harder synthetic base (long searches)
+if rest and rest[0] == "--kind":
+    base_kind, rest = rest[1], rest[2:]
 # hook combinations to compare: --combos "QUERY_EARLY=0;QUERY_EARLY=1,QUERY_GLOBAL_RING=0;..."
 combos = [{"QUERY_EARLY": 0}, {"QUERY_EARLY": 1}]
 if rest and rest[0] == "--combos":
@@ -24,10 +27,10 @@ if rest and rest[0] == "--combos":
     rest = rest[2:]
 points = [tuple(float(x) for x in p.split(":")) for p in rest] or [(0.85, 175)]
 dev = torch.device("cuda", 0)
-base = synthetic("lowrank16", n, d, 1234, dev)
-qs = {"tune": synthetic("lowrank16", 10_000, d, 4321, dev),
-      "held": synthetic("lowrank16", 10_000, d, 8642, dev)}
-big = synthetic("lowrank16", 100_000, d, 9876, dev)
+base = synthetic(base_kind, n, d, 1234, dev)
+qs = {"tune": synthetic(base_kind, 10_000, d, 4321, dev),
+      "held": synthetic(base_kind, 10_000, d, 8642, dev)}
+big = synthetic(base_kind, 100_000, d, 9876, dev)
 if kind == "u8":
     base, big = base.to(torch.uint8), big.to(torch.uint8)
     qs = {k: v.to(torch.uint8) for k, v in qs.items()}
