@@ -191,13 +191,15 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
 
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
 @pytest.mark.parametrize("K,tau,iters", [(10, 0.64, 175), (10, 0.9, 400), (40, 2.0, 448),
-                                         (10, 3.0, 256), (10, 1.0, 480)])
+                                         (10, 3.0, 256), (10, 1.0, 480), (10, 3.0, 600),
+                                         (40, 2.0, 960), (10, 3.0, 1900)])
 def test_query_orders_and_ring_homes_equal_the_oracle(ops, orc, small_graph, dtype, K, tau, iters):
     """The query kernel's order variants (hook QUERY_EARLY: first-read rows of a pop's neighbours
     requested before / after the pop's bookkeeping and the membership test; hook
     QUERY_GLOBAL_RING: visited ring of a 512-key cache in global memory / in LDS) against the
     oracle: ids, distances, n_dist, n_pop -- float32 with the pre-screen and uint8 rows (the two
-    early-rows layouts)."""
+    early-rows layouts).  600 / 960 / 1900 iterations: the 16-bit tag set of long rings (992 / 960 /
+    2016 keys), ring-less when the search cannot wrap."""
     from ggnn_amd import _lib
     g = small_graph
     base = g["base"] if dtype == "f32" else g["base"].astype(np.uint8)
