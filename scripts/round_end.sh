@@ -1,0 +1,28 @@
+#!/bin/bash
+# What is run on the GPU box before a round closes (one gpurun call, ~7 minutes):
+#   the whole -m gpu suite (4 workers), every rocprofv3 pass behind profiles/<tag>_* for the four
+#   BASELINE shapes, and the default `python bench.py` line.  The summaries land in
+#   gpurun_out/profiles_<tag>/ (gpurun only merges gpurun_out/ back): copy them into profiles/.
+#   The counter passes carry a fingerprint of the kernel sources: collect them AFTER the last
+#   change to traversal.hpp / query.hip / merge.hip / sym.hip, or bench.py ignores them.
+#     gpurun --timeout 3000 -- 'bash scripts/round_end.sh r05'
+cd "$GRAFT_REPO_ROOT" || exit 1
+tag=${1:-r05}
+mkdir -p gpurun_out/profiles_$tag
+export GRAFT_REPO_ROOT
+(timeout 1500 python -m pytest tests -q -m gpu -n 4 --dist loadfile --timeout 1200 2>&1 | tail -12) > gpurun_out/q_tests.log 2>&1
+bash scripts/profile_round.sh $tag > gpurun_out/q_prof_head.log 2>&1
+bash scripts/profile_round.sh $tag u8 --dtype u8 > gpurun_out/q_prof_u8.log 2>&1
+bash scripts/profile_round.sh $tag d96 --n-base 12500000 --dim 96 > gpurun_out/q_prof_d96.log 2>&1
+bash scripts/profile_round.sh $tag d960cos --dim 960 --measure cosine --tau-query 0.85 --max-iters 175 > gpurun_out/q_prof_d960.log 2>&1
+cd "$GRAFT_REPO_ROOT"
+cp profiles/${tag}_* gpurun_out/profiles_$tag/ 2>/dev/null
+(timeout 900 python bench.py > gpurun_out/profiles_$tag/${tag}_bench_n1.json 2> gpurun_out/q_bench.err)
+cat gpurun_out/q_tests.log
+python - <<PY
+import json
+d=json.load(open("gpurun_out/profiles_$tag/${tag}_bench_n1.json"))
+print({k:d[k] for k in ("value","ms_per_step","recall_at_10")}, "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "valu", d["roofline"]["secondary"]["valu_issue"].get("valu_insts_per_pop"))
+print({k:(v["at_recall_0.99"] or {}).get("queries_per_s") for k,v in d["recall_targets"]["results"].items()})
+print({k:d["build"][k]["roofline"]["bound"]+" %.3f"%d["build"][k]["roofline"]["frac"] for k in ("merge_kernel","sym_kernel")})
+PY
