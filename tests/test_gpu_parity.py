@@ -220,6 +220,44 @@ def test_query_orders_and_ring_homes_equal_the_oracle(ops, orc, small_graph, dty
         assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), (early, gring)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("KB", [1, 3, 8, 17, 23, 24])
+def test_query_early_rows_on_arbitrary_graph_rows(ops, orc, dtype, KB):
+    """The early-rows order requests the rows of ALL slots of a graph row before it knows which of
+    them are candidates at all.  Hand-made graphs (not built ones): rows with EMPTY (-1) slots,
+    the same neighbour several times in a row (the reference evaluates both copies: the membership
+    test runs before either is pushed), self loops, and every row width up to 24 -- ids, distances,
+    n_dist and n_pop must equal the oracle's in both orders."""
+    from ggnn_amd import _lib
+    N, D = 1500, 128
+    r = np.random.default_rng(700 + KB)
+    base = r.integers(0, 256, (N, D))
+    base = base.astype(np.uint8) if dtype == "u8" else base.astype(np.float32)
+    q = r.integers(0, 256, (60, D))
+    q = q.astype(np.uint8) if dtype == "u8" else q.astype(np.float32)
+    graph = r.integers(0, N, (N, KB)).astype(np.int32)
+    graph[r.random((N, KB)) < 0.15] = -1                       # EMPTY slots anywhere in a row
+    dup = r.random(N) < 0.3
+    if KB >= 3:
+        graph[dup, KB - 1] = graph[dup, 0]                      # a neighbour twice in one row
+    graph[::7, 0] = np.arange(0, N, 7)                          # self loops
+    graph[5] = -1                                               # a row without any neighbour
+    start = r.choice(N, 32, replace=False).astype(np.int32)
+    stats = np.array([900.0, 1400.0], np.float32)
+    o_ids, o_d, o_nd, o_np = orc.query(base, q, graph, start, stats, 10, 1.2, 150, counters=True)
+    b = dev(base)
+    ps = ops.prescreen_encode(b) if dtype == "f32" else None
+    for early in (1, 0):
+        with _lib.hooks(QUERY_EARLY=early):
+            ids, d, nd, npop = ops.query(b, dev(q), dev(graph), dev(start), dev(stats), 10, 1.2, 150,
+                                         counters=True, prescreen=ps)
+        assert np.array_equal(ids.cpu().numpy(), o_ids), early
+        assert np.array_equal(d.cpu().numpy(), o_d), early
+        assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), early
+        assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), early
+    assert int(o_np.max()) > 20
+
+
 @pytest.mark.parametrize("top,btm", [(3, 0), (2, 0), (2, 1)])
 def test_merge_orders_equal_the_oracle(ops, orc, small_graph, top, btm):
     """hook MERGE_EARLY = 1 | 0 (the same reordering in the merge kernel, upper layers go through
