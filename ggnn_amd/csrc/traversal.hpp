@@ -1608,6 +1608,10 @@ GGNN_DEV int fetch(SL& sl, const DE& de, const WaveLds& lds, int cand,
 // counters keep counting what the algorithm needs, not the extra rows of known candidates).
 // ---------------------------------------------------------------------------------------------
 constexpr int kEarlySteps = 3;  // 24 candidates
+// Candidate c = 3 * grp + s goes to the eight lanes of row group grp in step s, and its verdict is
+// taken in lane 8 * grp + s: ascending lanes are ascending candidates, so ONE ballot over the three
+// steps lists the candidates that pass in the order the replay needs (simple_knn_cache.cuh:268-286
+// evaluates them one after the other).
 template <class RD>  // RD: the reader of the first rows (Prescreen<8,1,.> or DistEngine<.,8,1>)
 struct EarlyRows {
   static_assert(RD::LPR == 8 && RD::NCH == 1, "early rows: 8 lanes x one 16-byte chunk per row");
@@ -1621,7 +1625,7 @@ struct EarlyRows {
     // the three crossbar reads first (one wait for all of them, not one round trip per step)
 #pragma unroll
     for (int s = 0; s < kEarlySteps; ++s)
-      kk[s] = __builtin_amdgcn_ds_bpermute((s * 8 + grp) << 2, cand);
+      kk[s] = __builtin_amdgcn_ds_bpermute((grp * kEarlySteps + s) << 2, cand);
     int m[kEarlySteps];
 #pragma unroll
     for (int s = 0; s < kEarlySteps; ++s) {
@@ -1647,7 +1651,30 @@ struct EarlyRows {
       }
     }
   }
+  // the value of step (lane & 7) in lanes whose (lane & 7) < 3 (their candidate's lane)
+  template <typename T>
+  static GGNN_DEV T of_my_step(const T (&x)[kEarlySteps])
+  {
+    const int w = threadIdx.x & 7;
+    return w == 0 ? x[0] : w == 1 ? x[1] : x[2];
+  }
 };
+
+// Pushes, in ascending lane order, the candidates of `m` (lane j: key k_of, distance d_of) that
+// still beat the criteria -- the replay of simple_knn_cache.cuh:268-286 (criteria() never increases
+// during a fetch, so a candidate that fails it once fails it later too)
+template <class SL>
+GGNN_DEV void replay_lanes(SL& sl, unsigned long long m, const int k_of, const float d_of)
+{
+  while (m) {
+    const int j = __ffsll(static_cast<long long>(m)) - 1;
+    m &= m - 1;
+    const float d = rdlanef(d_of, j);
+    const int k = rdlane(k_of, j);
+    if (d < sl.criteria())
+      sl.push(k, d);
+  }
+}
 
 // second half of a pop in the early-rows order: membership test, verdicts, exact phase, replay.
 // cand: lane j (< 24) holds candidate j or EMPTY (the value issue() was given).
@@ -1657,12 +1684,13 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
                          const int32_t* translation = nullptr)
 {
   const int lane = threadIdx.x;
-  const int grp = lane >> 3;
-  const bool g0 = (lane & 7) == 0;
+  const int grp = lane >> 3, w = lane & 7;
   cand = sl.template filter<false>(lower_half_to_both(cand), lds.known);
   const unsigned surv = static_cast<unsigned>(__ballot(lane < 32 && cand != kEmptyKey));
   const int nsurv = __popc(surv);
   after_filter();
+  // this lane's candidate (w < 3) survived the membership test
+  const bool alive = w < kEarlySteps && ((surv >> (grp * kEarlySteps + w)) & 1u);
   // rows.x / rows.y count the rows the ALGORITHM needs, as fetch() does (code rows of the
   // survivors of the membership test while the pre-screen is active, float rows of those that pass
   // it): the roofline's algorithmic bytes do not grow because this order also requests the rows of
@@ -1674,41 +1702,37 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
     const float s_thr = ps.threshold(sl.criteria());
     if (s_thr < inf_f())
       rows.y += nsurv;
-    int neval = 0;
+    float S[kEarlySteps];
 #pragma unroll
-    for (int s = 0; s < kEarlySteps; ++s) {
-      const float S = group_sum<8>(ps.partial(er.v[s]));
-      const bool pass = ((surv >> (s * 8 + grp)) & 1u) && g0 && !(S >= s_thr);
-      const unsigned long long pm = __ballot(pass);
-      if (pass)
-        lds.ckeys[neval + __popcll(pm & ((1ull << lane) - 1ull))] = er.kk[s];
-      neval += __popcll(pm);
-    }
+    for (int s = 0; s < kEarlySteps; ++s)
+      S[s] = group_sum<8>(ps.partial(er.v[s]));  // (every lane of the group holds the sum)
+    const bool pass = alive && !(ER::of_my_step(S) >= s_thr);
+    const unsigned long long pm = __ballot(pass);   // ascending lanes = ascending candidates
+    const int neval = __popcll(pm);
     if (neval == 0)
       return nsurv;
-    __syncthreads();
+    rows.x += neval;
+    const int mykey = ER::of_my_step(er.kk);
     constexpr int kSteps = StepsOf<DE::LPR, DE::NCH>::value;
     constexpr int kExactSteps = (DE::NCH == 3 && DE::ROWS >= 8) ? 1 : (kSteps > 2) ? 2 : kSteps;
+    // keys of the candidates that pass -> LDS in candidate order (one write: the ballot is already
+    // in that order), float rows, distances -> LDS, replay.  (Routing the ~3 keys through scalar
+    // registers to the row groups and keeping the distances in their lanes -- no LDS between the
+    // verdicts and the replay -- was measured: identical results, 10k-query batch unchanged, 100k
+    // batch and build -2 %; not worth a second code path.  DESIGN.md Appendix B.)
+    if (pass)
+      lds.ckeys[__popcll(pm & ((1ull << lane) - 1ull))] = mykey;
+    __syncthreads();
     compute_distances<MODE, DE, kExactSteps>(de, lds, neval, translation);
-    rows.x += neval;
     __syncthreads();
     const float cd = lane < neval ? lds.cd0[lane] : inf_f();
     const int ck = lane < neval ? lds.ckeys[lane] : kEmptyKey;
-    // criteria() never increases during a fetch, so candidates failing it now fail it later
-    unsigned long long m = __ballot(cd < sl.criteria());
-    while (m) {
-      const int j = __ffsll(static_cast<long long>(m)) - 1;
-      m &= m - 1;
-      const float d = rdlanef(cd, j);
-      const int k = rdlane(ck, j);
-      if (d < sl.criteria())
-        sl.push(k, d);
-    }
+    replay_lanes(sl, __ballot(cd < sl.criteria()), ck, cd);
     return nsurv;
   }
   else {
-    // the requested rows ARE the base rows: distances stay in the lanes that summed them (lane
-    // grp*8 of step s = candidate s*8 + grp), the replay reads them from there in candidate order
+    // the requested rows ARE the base rows: distances stay in the lanes that summed them (every
+    // lane of a group holds the sum), the replay reads lane 8 * grp + s for candidate 3 * grp + s
     rows.x += nsurv;
     if (nsurv == 0)
       return 0;
@@ -1722,20 +1746,8 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
         b = group_sum<8>(b);
       dd[s] = (MODE == kCos) ? de.finish_cos(a, b) : a;
     }
-    const float crit = sl.criteria();
-#pragma unroll
-    for (int s = 0; s < kEarlySteps; ++s) {
-      unsigned long long m =
-          __ballot(((surv >> (s * 8 + grp)) & 1u) && g0 && dd[s] < crit);
-      while (m) {
-        const int j = __ffsll(static_cast<long long>(m)) - 1;
-        m &= m - 1;
-        const float d = rdlanef(dd[s], j);
-        const int k = rdlane(er.kk[s], j);
-        if (d < sl.criteria())
-          sl.push(k, d);
-      }
-    }
+    const float dmine = ER::of_my_step(dd);
+    replay_lanes(sl, __ballot(alive && dmine < sl.criteria()), ER::of_my_step(er.kk), dmine);
     return nsurv;
   }
 }
