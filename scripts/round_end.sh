@@ -8,9 +8,12 @@
 #     gpurun --timeout 3000 -- 'bash scripts/round_end.sh r05'
 cd "$GRAFT_REPO_ROOT" || exit 1
 tag=${1:-r05}
+# optional second argument: the test files to run instead of the whole -m gpu suite (when only a
+# scheduling detail of a kernel changed after the last full run and GPU minutes are short)
+sel=${2:-tests}
 mkdir -p gpurun_out/profiles_$tag
 export GRAFT_REPO_ROOT
-(timeout 1500 python -m pytest tests -q -m gpu -n 4 --dist loadfile --timeout 1200 2>&1 | tail -12) > gpurun_out/q_tests.log 2>&1
+(timeout ${TEST_TIMEOUT:-1500} python -m pytest $sel -q -m gpu ${PYTEST_DIST:--n 4 --dist loadfile} --timeout 1200 2>&1 | tail -12) > gpurun_out/q_tests.log 2>&1
 bash scripts/profile_round.sh $tag > gpurun_out/q_prof_head.log 2>&1
 bash scripts/profile_round.sh $tag u8 --dtype u8 > gpurun_out/q_prof_u8.log 2>&1
 bash scripts/profile_round.sh $tag d96 --n-base 12500000 --dim 96 > gpurun_out/q_prof_d96.log 2>&1
