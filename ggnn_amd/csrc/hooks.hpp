@@ -26,7 +26,7 @@ enum Hook {
   kHookBfNoCenter,      // BF_NO_CENTER     1 = rows not shifted by the column mean
   kHookBfTiles,         // BF_TILES         2 | 4 base tiles per accumulator group (D > 128)
   kHookBfI8NoShare,     // BF_I8_NOSHARE    1 = slices do not share their bound
-  kHookBfI8Ranks,       // BF_I8_RANKS      bit mask of the set positions the slices exchange (-1 = all)
+  kHookBfI8Ranks,       // BF_I8_RANKS      bit mask of the set positions the slices exchange (-1 = auto: one, 31 = all)
   kHookBfScan,          // BF_SCAN          1 = scan kernels instead of the matrix-core path
   kHookRcclFailAfter,   // RCCL_FAIL_AFTER  fault injection: the n-th exchange (1-based) reports an
                         //                  RCCL failure (0 = never); exercises the peer-copy fallback
@@ -37,6 +37,7 @@ enum Hook {
   kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = early-rows kernels keep a visited ring in LDS even when it cannot wrap
   kHookBfI8Refresh,     // BF_I8_REFRESH    stages between bound exchanges of the i8 kernel's slices
   kHookBfI8Seed,        // BF_I8_SEED       rows of the i8 kernel's seeding launch (0 = none)
+  kHookQueryPair,       // QUERY_PAIR       0 = never two searches per wave (query_pair.hip)
   kHookCount
 };
 

@@ -15,6 +15,7 @@ merge then uses the device-independent torch implementation below.
 import torch
 import torch.distributed as dist
 
+from ._lib import UNSUPPORTED
 from .api import GGNN, DistanceMeasure, _as_tensor
 
 
@@ -114,23 +115,46 @@ class ShardedGGNN:
         split = self.split_blocking if self.split_blocking is not None else nq >= 4096
         if split and nq >= 2 and self._can_split(t):
             h = nq // 2
-            first = None
+            tickets, err, code = [], None, 0
             try:
-                first = self.query_async(t[:h], k_query, tau_query, max_iterations, measure, slot=0)
-            except RuntimeError:
-                # the asynchronous lanes are stricter than the blocking call (an engine whose
-                # shards take turns on the GPU refuses them, GGNN_UNSUPPORTED): every rank sees the
-                # same refusal before any collective was entered, so all fall back together
-                first = None
-            if first is not None:
-                second = self.query_async(t[h:], k_query, tau_query, max_iterations, measure, slot=1)
-                a = self.finish(first)
-                b = self.finish(second)
+                tickets.append(self.query_async(t[:h], k_query, tau_query, max_iterations, measure,
+                                                slot=0))
+                tickets.append(self.query_async(t[h:], k_query, tau_query, max_iterations, measure,
+                                                slot=1))
+            except Exception as e:   # noqa: BLE001 -- classified, agreed on and re-raised below
+                # 1: the asynchronous lanes refuse what the blocking call accepts (an engine whose
+                # shards take turns on the GPU: GGNN_UNSUPPORTED) -> fall back; 2: a real failure
+                # (out of memory, device error, ...) -> raise.  Either may happen on ONE rank only
+                # (swapping depends on the rank's free memory), so the ranks AGREE on the path
+                # before any of them enters a data collective: a rank that fell back alone would
+                # issue one all-gather of nq rows while its peers issue two of nq / 2.
+                err, code = e, (1 if getattr(e, "status", None) == UNSUPPORTED else 2)
+            worst = self._agree(code)
+            if worst == 0:
+                a = self.finish(tickets[0])
+                b = self.finish(tickets[1])
                 self.last_query_parts = 2
                 return torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+            for tk in tickets:          # what this rank did enqueue is drained and dropped
+                self.engine.synchronize(tk[2])
+            if worst >= 2:
+                if code == 2:
+                    raise err
+                raise RuntimeError("ShardedGGNN.query: another rank failed to enqueue its local "
+                                   "search; no collective was entered")
         self.last_query_parts = 1
         ids, dists = self.engine.query(t, k_query, tau_query, max_iterations, measure)
         return self._exchange(ids, dists, int(k_query))
+
+    def _agree(self, code):
+        """MAX over the ranks of a small status code (one 4-byte all-reduce; the searches that
+        were enqueued run meanwhile on the engine's own streams)"""
+        if self.world_size == 1:
+            return code
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        f = torch.tensor([code], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+        return int(f.item())
 
     def _can_split(self, t):
         """the preconditions of the engine's asynchronous lanes, as the C-level split checks them

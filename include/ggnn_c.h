@@ -243,9 +243,9 @@ void ggnn_set_log_level(int level);
  *   BF_TILES            3     2 | 3 | 4 base tiles per accumulator group (D > 128)
  *   BF_I8_NOSHARE       0     1 = slices of the i8 kernel do not share their bound
  *   BF_I8_RANKS        -1     bit mask of the K-best set positions the slices of the i8 kernel
- *                             exchange (bit i = the i-th of {0,1,2,4,9} for sets of 10); -1 = all,
- *                             16 = only the last entry (the single shared bound of rounds 3-4);
- *                             default: one position chosen from the number of slices
+ *                             exchange (bit i = the i-th of {0,1,2,4,9} for sets of 10); -1 = auto
+ *                             (ONE position chosen from the number of slices: the default), 31 = all
+ *                             five, 16 = only the last entry (the single shared bound of rounds 3-4)
  *   BF_I8_REFRESH      64     stages of 128 rows between those exchanges (before that: at stages
  *                             1, 2, 4, ...)
  *   BF_I8_SEED          0     rows of an optional seeding launch of the i8 kernel (the K-th best
@@ -264,7 +264,12 @@ void ggnn_set_log_level(int level);
  *   QUERY_GLOBAL_RING   1     early-rows query kernels whose search cannot wrap its visited ring
  *                             (max_iterations <= ring length): 1 = no ring at all, the hashed set's
  *                             buckets and stash ARE the visited keys (overflow list in global
- *                             memory); 0 = ring in LDS mirrored by the set */
+ *                             memory); 0 = ring in LDS mirrored by the set
+ *   QUERY_PAIR          1     searches whose sorted part is 32 keys (257+ iterations, KQuery <= 15)
+ *                             and that cannot wrap their visited ring: 1 = TWO searches per wave64,
+ *                             one per half-wave in lockstep (query_pair.hip); 0 = one search per
+ *                             wave (same results); 2 = test setting: a launch that kernel does not
+ *                             serve fails with GGNN_UNSUPPORTED */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);
