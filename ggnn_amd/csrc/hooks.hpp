@@ -37,7 +37,6 @@ enum Hook {
   kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = early-rows kernels keep a visited ring in LDS even when it cannot wrap
   kHookBfI8Refresh,     // BF_I8_REFRESH    stages between bound exchanges of the i8 kernel's slices
   kHookBfI8Seed,        // BF_I8_SEED       rows of the i8 kernel's seeding launch (0 = none)
-  kHookQueryPair,       // QUERY_PAIR       0 = never two searches per wave (query_pair.hip)
   kHookCount
 };
 

@@ -9,11 +9,6 @@
 namespace ggnn_amd {
 
 
-// two searches per wave (query_pair.hip)
-bool query_pair_eligible(const QueryLaunch& a, uint32_t sorted, uint32_t cache);
-bool launch_query_pair(const QueryArgs& args, ggnn_dtype dtype, ggnn_measure measure, bool use_ps,
-                       hipStream_t stream);
-
 template <class PSC, typename BaseT>
 GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 {
@@ -467,9 +462,7 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   const bool global_ring = args.sorted <= 64 && vis_hash_regs(vis) != 0 && a.max_iterations <= vis &&
                            a.KBuild <= 8 * kEarlySteps && hook(kHookQueryEarly) != 0 &&
                            hook(kHookQueryGlobalRing) != 0;
-  // two searches per wave (query_pair.hip): their overflow lists are the same scratch
-  const bool pair = query_pair_eligible(a, args.sorted, args.cache);
-  if (pair || global_ring ||
+  if (global_ring ||
       (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0)) {
     args.tag_bits = global_ring ? 0 : tag_set_bucket_bits(vis);
     try {
@@ -504,14 +497,6 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
     args.ps_params = a.ps_params;
     args.ps_Dc = a.ps_Dc;
   }
-  if (pair && launch_query_pair(args, a.dtype, a.measure, use_ps, stream)) {
-    GGNN_HIP_CHECK(hipGetLastError());
-    return;
-  }
-  // (test hook QUERY_PAIR = 2: a launch the pair kernel does not serve is an error, so that a test
-  // of that kernel cannot pass on another one)
-  GGNN_REQUIRE(hook(kHookQueryPair) != 2, GGNN_UNSUPPORTED,
-               "QUERY_PAIR=2: this launch is not served by the two-searches-per-wave kernel");
 
 #define GGNN_LAUNCH_QUERY(T, LPR, NCH) launch_query_cfg<T, LPR, NCH>(args, use_ps, a.measure, stream)
   GGNN_DISPATCH_DIST(a.dtype, a.D, GGNN_LAUNCH_QUERY);

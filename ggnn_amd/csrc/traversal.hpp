@@ -198,9 +198,12 @@ inline uint32_t vis_hash_regs(uint32_t vis)
 //     the set overflows -- both rare), and
 //   * the set keeps 16-bit TAGS: with M = nb_bits + 16 >= bits(N_base - 1), k -> (k * C) mod 2^M
 //     (C odd) is a bijection on the keys, so (bucket = its top nb_bits, tag = its low 16 bits)
-//     identifies the key EXACTLY -- no false positives, 2 bytes per key: 256 buckets x 8 tags =
-//     4 KB for a 992-key ring.  Buckets fill from slot 0 and a byte per bucket counts the slots in
-//     use (tags are never removed), the probe masks the others.
+//     identifies the key EXACTLY -- no false positives, 2 bytes per key: 256 buckets x 16 bytes =
+//     4 KB for a 992-key ring.  A bucket is SEVEN tags + the number of tags in use in its eighth
+//     halfword (round 6; rounds 4-5 kept eight tags and a count byte elsewhere): one 16-byte read
+//     brings both, buckets fill from slot 0 (tags are never removed), the probe masks the others.
+//     With the candidate scratch cut to what the query kernels use this is 5.0 KB of LDS per wave
+//     incl. the float query row -- 5.4 KB were 26 waves per CU, one less than the registers allow.
 // A full bucket sends the key to the stash as before; a stash overflow, or the first wrap of the
 // ring, switches to the scan of the global ring for the rest of the search (exact in every case).
 // HB = -nb_bits selects the tag set with 2^nb_bits buckets (a compile-time constant: the table
@@ -210,11 +213,14 @@ constexpr bool is_tag_set(int hb)
   return hb < 0;
 }
 constexpr uint32_t kTagMul = 0x9E3779B1u;
-// buckets (log2) for a ring of `vis` keys: load factor <= 0.5 with 8 tags per bucket
+constexpr int kTagSlots = 7;          // tags per 16-byte bucket (the eighth halfword counts them)
+constexpr int kTagScratchInts = 64;   // candidate scratch of the tag-set kernels: ckeys[32] | cd0[32]
+// buckets (log2) for a ring of `vis` keys: load factor <= 0.57 with 7 tags per bucket (256 buckets
+// for 992 keys, 512 for 2016)
 inline uint32_t tag_set_bucket_bits(uint32_t vis)
 {
   uint32_t b = 5;
-  while ((8u << b) < 2 * vis)
+  while ((static_cast<uint32_t>(kTagSlots) << b) * 4 < 7 * vis)
     ++b;
   return b;
 }
@@ -226,11 +232,11 @@ inline bool tag_set_usable(uint32_t vis, uint32_t n_base)
   const uint32_t m = tag_set_bucket_bits(vis) + 16;
   return m >= 32 || (static_cast<uint64_t>(n_base) <= (1ull << m));
 }
-// LDS of one wave: known[sorted] | candidate scratch | tags | counts | stash
+// LDS of one wave: known[sorted] | ckeys[32] | cd0[32] | buckets (16 bytes each) | stash
 __host__ __device__ inline size_t tag_set_lds_ints(uint32_t sorted, uint32_t nb_bits)
 {
   const size_t nb = size_t{1} << nb_bits;
-  return sorted + WaveLds::extra_ints + kVisStash + (nb * 16 + nb) / 4;
+  return sorted + kTagScratchInts + kVisStash + nb * 4;
 }
 inline size_t tag_set_lds_bytes(uint32_t sorted, uint32_t vis)
 {
@@ -291,11 +297,6 @@ struct SortedList {
   static constexpr bool kTag = is_tag_set(HB);
   static constexpr int nb_bits = kTag ? -HB : 0;
   int* ring_g;                // [VIS] visited ring of this search in global memory
-  // [2^nb_bits] tags in use per bucket, behind the tags
-  GGNN_DEV unsigned char* tcnt() const
-  {
-    return reinterpret_cast<unsigned char*>(hbuckets + (4 << nb_bits));
-  }
 
   GGNN_DEV void init(int best, int sorted, int cache, float xi_, int* known,
                      int usable_slots = kVisSlots)
@@ -335,10 +336,10 @@ struct SortedList {
     P = sorted - best;
     VIS = cache - sorted;
     xi = xi_;
-    slots = usable_slots;
+    slots = usable_slots < kTagSlots ? usable_slots : kTagSlots;
     ring_g = ring;
-    hbuckets = known + sorted + static_cast<int>(WaveLds::extra_ints);  // tags, 4 ints per bucket
-    hstash = hbuckets + (4 << nb_bits) + ((1 << nb_bits) >> 2);
+    hbuckets = known + sorted + kTagScratchInts;  // 4 ints per bucket: 7 tags + their number
+    hstash = hbuckets + (4 << nb_bits);
     reset(known);
   }
   // visited ring (and its hashed mirror) empty, simple_knn_cache.cuh:73-87
@@ -348,11 +349,10 @@ struct SortedList {
     vis_count = 0;
     ovf_n = 0;
     if constexpr (kTag) {
-      // counts to zero; tags need no clearing (masked by the counts), the global ring is only
-      // ever read below vis_count
-      int* c = reinterpret_cast<int*>(tcnt());
-      for (int i = threadIdx.x; i < ((1 << nb_bits) >> 2); i += kWave)
-        c[i] = 0;
+      // counts (the upper half of a bucket's last word) to zero; tags need no clearing (masked
+      // by the counts), the global ring is only ever read below vis_count
+      for (int i = threadIdx.x; i < (1 << nb_bits); i += kWave)
+        hbuckets[i * 4 + 3] = 0;
       stash_n = 0;
       scan_mode = 0;
       return;
@@ -472,19 +472,19 @@ struct SortedList {
   {
     const uint32_t h = tag_hash(static_cast<uint32_t>(k));
     const uint32_t b = h >> 16;
-    const int c = uni(tcnt()[b]);
+    // lane l reads halfword (l & 7) of the bucket: lanes 0-6 a tag, lane 7 the number of tags
+    const int lane = threadIdx.x;
+    unsigned short* bucket = reinterpret_cast<unsigned short*>(hbuckets) + b * 8;
+    const int mine = bucket[lane & 7];
+    const int c = rdlane(mine, 7);
     // A key can be popped more than once (quirk Q1 duplicates a queue entry when the ring of the
     // priority queue has wrapped): the set keeps it once, or its copies would fill their bucket
-    const int lane = threadIdx.x;
-    const unsigned short mine =
-        reinterpret_cast<const unsigned short*>(hbuckets)[b * kVisSlots + (lane & (kVisSlots - 1))];
-    if (__any(lane < c && mine == static_cast<unsigned short>(h & 0xffffu)))
+    if (__any(lane < c && mine == static_cast<int>(h & 0xffffu)))
       return;
     if (c < slots) {
       if (threadIdx.x == 0) {
-        reinterpret_cast<unsigned short*>(hbuckets)[b * kVisSlots + c] =
-            static_cast<unsigned short>(h & 0xffffu);
-        tcnt()[b] = static_cast<unsigned char>(c + 1);
+        bucket[c] = static_cast<unsigned short>(h & 0xffffu);
+        bucket[7] = static_cast<unsigned short>(c + 1);
       }
     }
     else if (stash_n < kVisStash) {
@@ -791,21 +791,22 @@ struct SortedList {
     unsigned acc0 = 0xffffffffu, acc1 = 0xffffffffu;
     if constexpr (kTag) {
       if (hashed) {
-        // lower half-wave: candidate j probes its bucket (8 tags = one 16-byte read, slots in use
-        // from the count byte); upper half-wave: the stash
+        // lower half-wave: candidate j probes its bucket (one 16-byte read: 7 tags and, in the
+        // last halfword, how many of them are in use); upper half-wave: the stash
         const uint32_t hh = tag_hash(c);
         const uint32_t b = hh >> 16;
         const uint32_t tt = (hh & 0xffffu) * 0x10001u;
         if (h == 0) {
           const int4 w = *reinterpret_cast<const int4*>(hbuckets + b * 4);
-          const int v = tcnt()[b];
+          const int v = static_cast<int>(static_cast<unsigned>(w.w) >> 16);
           auto pair = [tt, v](unsigned a, int wv, int slot) {
             const unsigned x = static_cast<unsigned>(wv) ^ tt;
             const unsigned lo = slot < v ? (x & 0xffffu) : 1u;
             const unsigned hi = slot + 1 < v ? (x >> 16) : 1u;
             return min(a, min(lo, hi));
           };
-          acc1 = pair(pair(pair(pair(acc1, w.x, 0), w.y, 2), w.z, 4), w.w, 6);
+          acc1 = pair(pair(pair(acc1, w.x, 0), w.y, 2), w.z, 4);
+          acc1 = min(acc1, 6 < v ? ((static_cast<unsigned>(w.w) ^ tt) & 0xffffu) : 1u);
         }
         else {
           for (int t = 0; t < stash_n; ++t)

@@ -264,12 +264,7 @@ void ggnn_set_log_level(int level);
  *   QUERY_GLOBAL_RING   1     early-rows query kernels whose search cannot wrap its visited ring
  *                             (max_iterations <= ring length): 1 = no ring at all, the hashed set's
  *                             buckets and stash ARE the visited keys (overflow list in global
- *                             memory); 0 = ring in LDS mirrored by the set
- *   QUERY_PAIR          1     searches whose sorted part is 32 keys (257+ iterations, KQuery <= 15)
- *                             and that cannot wrap their visited ring: 1 = TWO searches per wave64,
- *                             one per half-wave in lockstep (query_pair.hip); 0 = one search per
- *                             wave (same results); 2 = test setting: a launch that kernel does not
- *                             serve fails with GGNN_UNSUPPORTED */
+ *                             memory); 0 = ring in LDS mirrored by the set */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);

@@ -100,17 +100,38 @@ def _worker(rank, world, port, tmp):
         assert torch.equal(ids2, ids) and torch.equal(d2, d)
         ids3, d3 = sg.query(query[:7], K, 0.6, 200)       # odd count: halves of 3 and 4
         assert torch.equal(ids3, ids[:7]) and torch.equal(d3, d[:7])
-        # an engine whose asynchronous lanes refuse the batch (the real one does for shards that
-        # take turns on the GPU: GGNN_UNSUPPORTED): the split falls back to ONE blocking search +
-        # one exchange on every rank, same result (round-4 advisor finding)
+        # An engine whose asynchronous lanes refuse the batch (the real one does for shards that
+        # take turns on the GPU: GGNN_UNSUPPORTED) ON ONE RANK ONLY -- swapping depends on the
+        # rank's free memory: the ranks agree on the path before any data collective, all fall back
+        # to ONE blocking search + one exchange, same result (round-5 advisor finding: a rank that
+        # fell back alone would issue one all-gather of nq rows against its peers' two of nq / 2)
+        from ggnn_amd._lib import GGNNError, UNSUPPORTED
         real_async = sg.engine.query_async
 
         def refusing(*a, **kw):
-            raise RuntimeError("query_async: not available while shards are swapped")
-        sg.engine.query_async = refusing
+            raise GGNNError(UNSUPPORTED, "query_async: not available while shards are swapped")
+        if rank == world - 1:
+            sg.engine.query_async = refusing
         ids4, d4 = sg.query(query, K, 0.6, 200)
         assert sg.last_query_parts == 1
         assert torch.equal(ids4, ids) and torch.equal(d4, d)
+        # any OTHER failure on one rank (out of memory, device error ...) is an error on every
+        # rank, raised before a collective is entered -- not a silent fallback, not a hang
+
+        def failing(*a, **kw):
+            raise MemoryError("out of memory allocating the result buffers")
+        sg.engine.query_async = failing if rank == 0 else real_async
+        try:
+            sg.query(query, K, 0.6, 200)
+            raise AssertionError("a failure on one rank must surface on every rank")
+        except MemoryError:
+            assert rank == 0
+        except RuntimeError as e:
+            assert rank != 0 and "another rank failed" in str(e)
+        # ... and the group is still usable afterwards
+        sg.engine.query_async = real_async
+        ids5, d5 = sg.query(query, K, 0.6, 200)
+        assert sg.last_query_parts == 2 and torch.equal(ids5, ids) and torch.equal(d5, d)
         sg.engine.query_async = real_async
         sg.split_blocking = None
         with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
@@ -126,6 +147,97 @@ def test_sharded_query_gloo_world2(tmp_path, orc):
     s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+class OracleShardsEngine(OracleEngine):
+    """the stand-in with several shards per rank (GGNN::setShardSize on the rank's slice): one
+    independent graph per shard, the local result is the reference's per-GPU row -- the K results
+    of every shard with ids offset by on_gpu_shard * N_shard, sorted (gpu_instance.cu:745-790)"""
+
+    def set_shard_size(self, n_shard):
+        self.n_shard = int(n_shard)
+
+    def build(self, k_build, tau_build, refinement_iterations=2, measure=0):
+        n = self.n_shard
+        self.shards = []
+        for lo in range(0, self.base.shape[0], n):
+            b = self.base[lo:lo + n]
+            self.shards.append((b,) + tuple(self.orc.build(
+                b, k_build, tau_build, refinement_iterations, int(measure),
+                rng=self.orc.make_rng(n, 7), threads=1)))
+
+    def query(self, query, k, tau, iters=400, measure=0):
+        q = query.numpy()
+        ids, ds = [], []
+        for s, (b, c, graph, tr, sel, stats) in enumerate(self.shards):
+            start = tr[c.STs_offsets[3]:c.STs_offsets[3] + c.Ns[3]]
+            i, d = self.orc.query(b, q, graph[:c.N], start, stats, k, tau, iters, int(measure),
+                                  threads=1)
+            ids.append(i + s * self.n_shard)
+            ds.append(d)
+        i, d = self.orc.sort_shard_results(np.concatenate(ids, 1), np.concatenate(ds, 1))
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+
+def _worker8(rank, world, port, tmp):
+    """what an 8-GPU node runs first: 8 ranks, two shards per rank, a query count that 8 does not
+    divide, blocking (split into two half-batches of different sizes) and batches in flight"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_int_data
+        from ggnn_amd.distributed import ShardedGGNN
+        from oracle import oracle as orc
+        N, D, K, NSH = 3200, 16, 10, 200            # 8 ranks x 2 shards x 200 points
+        base = torch.from_numpy(make_int_data(N, D, 15))
+        query = torch.from_numpy(make_int_data(37, D, 16))   # 37 = 8 * 4 + 5
+        sg = ShardedGGNN(engine=OracleShardsEngine())
+        sg.set_base(base)
+        assert sg.n_local == N // world
+        sg.set_shard_size(NSH)
+        sg.build(16, 0.5, 0)
+        l_ids, l_d = sg.engine.query(query, K, 0.7, 100)
+        assert l_ids.shape == (37, 2 * K)
+        parts_i = [torch.empty_like(l_ids) for _ in range(world)]
+        parts_d = [torch.empty_like(l_d) for _ in range(world)]
+        dist.all_gather(parts_i, l_ids)
+        dist.all_gather(parts_d, l_d)
+        # the reference's ResultMerger over the 8 per-GPU rows: id offset g * shards_per_gpu * N_shard
+        r_ids, r_d = orc.merge_results([p.numpy() for p in parts_i], [p.numpy() for p in parts_d],
+                                       K, 2, NSH)
+        for split in (False, True):
+            sg.split_blocking = split
+            ids, d = sg.query(query, K, 0.7, 100)
+            assert sg.last_query_parts == (2 if split else 1)
+            assert np.array_equal(d.numpy(), r_d), split
+            uniq = np.ones_like(r_ids, bool)
+            uniq[:, 1:] &= r_d[:, 1:] != r_d[:, :-1]
+            uniq[:, :-1] &= r_d[:, :-1] != r_d[:, 1:]
+            assert np.array_equal(ids.numpy()[uniq], r_ids[uniq]), split
+            assert ids.numpy().min() >= 0 and ids.numpy().max() < N
+        # two batches in flight, finished in order
+        t0 = sg.query_async(query[:20], K, 0.7, 100, slot=0)
+        t1 = sg.query_async(query[20:], K, 0.7, 100, slot=1)
+        a, b = sg.finish(t0), sg.finish(t1)
+        assert np.array_equal(torch.cat([a[1], b[1]]).numpy(), r_d)
+        # exact brute force through the sharded path
+        ids, d = sg.bf_query(query, K)
+        g_ids, g_d = orc.bf_query(base.numpy(), query.numpy(), K)
+        assert np.array_equal(d.numpy(), g_d)
+        with open(os.path.join(tmp, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_query_gloo_world8_two_shards_per_rank(tmp_path, orc):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(8))
 
 
 def test_merge_gathered_cpu_matches_oracle(orc):

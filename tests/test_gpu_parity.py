@@ -210,66 +210,14 @@ def test_query_orders_and_ring_homes_equal_the_oracle(ops, orc, small_graph, dty
                                        counters=True)
     b = dev(base)
     ps = ops.prescreen_encode(b) if dtype == "f32" else None
-    # (QUERY_PAIR = 1 | 0: two searches per wave where the sorted part is 32 keys, query_pair.hip)
-    for early, gring, pair in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 1, 0)):
-        with _lib.hooks(QUERY_EARLY=early, QUERY_GLOBAL_RING=gring, QUERY_PAIR=pair):
+    for early, gring in ((1, 1), (1, 0), (0, 1)):
+        with _lib.hooks(QUERY_EARLY=early, QUERY_GLOBAL_RING=gring):
             ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start_points(g)),
                                          dev(g["stats"]), K, tau, iters, counters=True, prescreen=ps)
-        assert np.array_equal(ids.cpu().numpy(), o_ids), (early, gring, pair)
-        assert np.array_equal(d.cpu().numpy(), o_d), (early, gring, pair)
-        assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), (early, gring, pair)
-        assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), (early, gring, pair)
-
-
-_PAIR_CASES = {}
-
-
-def _pair_case(orc, dtype, D):
-    """oracle-built graph per (element type, D), shared by the cases of the test below"""
-    if (dtype, D) not in _PAIR_CASES:
-        N = 2000
-        r = np.random.default_rng(5000 + D)
-        base = r.integers(0, 256, (N, D))
-        base = base.astype(np.uint8) if dtype == "u8" else base.astype(np.float32)
-        q = r.integers(0, 256, (61, D))
-        q = q.astype(np.uint8) if dtype == "u8" else q.astype(np.float32)
-        cfg, graph, tr, sel, stats = orc.build(base, 24, 0.5, 1, 0, rng=orc.make_rng(N, 11), threads=4)
-        start = tr[cfg.STs_offsets[3]:cfg.STs_offsets[3] + cfg.Ns[3]]
-        _PAIR_CASES[(dtype, D)] = (base, q, graph[:N].copy(), start.copy(), stats)
-    return _PAIR_CASES[(dtype, D)]
-
-
-@pytest.mark.parametrize("dtype,D", [("f32", 128), ("f32", 96), ("f32", 64), ("f32", 32), ("u8", 128),
-                                     ("u8", 64)])
-@pytest.mark.parametrize("K,tau,iters,slots", [(10, 0.4, 280, 8), (10, 1.0, 300, 8), (15, 3.0, 320, 8),
-                                               (10, 3.0, 480, 8), (1, 1.0, 400, 8), (10, 3.0, 800, 8),
-                                               (10, 2.0, 1900, 8), (10, 3.0, 300, 1), (10, 3.0, 900, 2)])
-def test_query_pair_kernel_equals_the_oracle(ops, orc, dtype, D, K, tau, iters, slots):
-    """Two searches per wave64 (query_pair.hip; hook QUERY_PAIR = 2: the launch fails unless that
-    kernel serves it): an ODD number of queries (the last wave's upper half idles), searches of very
-    different lengths in one wave (tau 0.4: 90 to 270 pops, the partner of a finished search goes on), every float
-    layout behind the 128-byte code rows and uint8 rows read directly, all three tag-set shapes
-    (<= 320 / <= 992 / <= 2016 iterations), shrunk buckets (stash and overflow list) -- ids,
-    distances, n_dist and n_pop equal the oracle's."""
-    from ggnn_amd import _lib
-    base, q, graph0, start, stats = _pair_case(orc, dtype, D)
-    o_ids, o_d, o_nd, o_np = orc.query(base, q, graph0, start, stats, K, tau, iters, counters=True)
-    b = dev(base)
-    ps = ops.prescreen_encode(b) if dtype == "f32" else None
-    with _lib.hooks(QUERY_PAIR=2, VIS_SLOTS=slots):
-        ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start), dev(stats), K, tau, iters,
-                                     counters=True, prescreen=ps)
-    assert np.array_equal(ids.cpu().numpy(), o_ids)
-    assert np.array_equal(d.cpu().numpy(), o_d)
-    assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
-    assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
-    if tau == 0.4:
-        assert int(o_np.min()) < int(o_np.max()) * 2 // 3, "searches of very different lengths"
-    # not served: a 64-key sorted part (K = 16), a search that can wrap its ring
-    for k2, it2 in ((16, 300), (10, 500)):
-        with _lib.hooks(QUERY_PAIR=2):
-            with pytest.raises(RuntimeError):
-                ops.query(b, dev(q), dev(graph0), dev(start), dev(stats), k2, 1.0, it2, prescreen=ps)
+        assert np.array_equal(ids.cpu().numpy(), o_ids), (early, gring)
+        assert np.array_equal(d.cpu().numpy(), o_d), (early, gring)
+        assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), (early, gring)
+        assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), (early, gring)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
