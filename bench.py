@@ -35,6 +35,7 @@ import argparse
 import glob
 import hashlib
 import json
+import socket
 import os
 import sys
 import time
@@ -421,6 +422,14 @@ def sift1m_real(directory, ggnn, device):
     gt, _ = eng.bf_query(q, 10)
     out = {"N": int(b.shape[0]), "Nq": int(q.shape[0]),
            "graph_build_s": eng.last_timing_ms()["build_ms"] / 1e3, "points": {}}
+    # the dataset's own ground truth (TEXMEX: 100 neighbours per query), when the file is there:
+    # recall is quoted against IT as well, and the engine's exact brute force has to agree with it
+    # (up to exact distance ties, which real SIFT has: equal rows are counted by distance)
+    gt_file = None
+    gt_path = os.path.join(directory, "sift_groundtruth.ivecs")
+    if os.path.exists(gt_path):
+        gt_file = ggnn.IntDataset.load(gt_path).view.to(device)[:, :10].contiguous()
+        out["groundtruth_file"] = {"K": 10, "bf_query_agrees_at_10": recall_at_k(gt, gt_file)}
     for tau, iters, target in ((0.34, 200, "c@1 ~0.90"), (0.41, 200, "c@1 ~0.95"),
                                (0.51, 200, "c@1 ~0.99"), (0.64, 400, "c@10 ~0.99")):
         for _ in range(3):
@@ -430,6 +439,9 @@ def sift1m_real(directory, ggnn, device):
             "published_target": target, "c_at_1": (ids[:, 0] == gt[:, 0]).float().mean().item(),
             "c_at_10": recall_at_k(ids, gt), "query_kernel_ms": ms,
             "queries_per_s": q.shape[0] / (ms * 1e-3)}
+        if gt_file is not None:
+            out["points"][f"tau={tau},iters={iters}"]["c_at_10_vs_groundtruth_file"] = \
+                recall_at_k(ids, gt_file)
     return out
 
 
@@ -876,32 +888,58 @@ def exchange_group(args, device, world, rank, cpu_group):
     all_gather_into_tensor on the device; if that raises on ANY rank, every rank falls back to the
     host-staged gloo exchange -- LOUDLY (stderr and `exchange.fallback` in the JSON line), so that a
     run can never silently measure the copy path while the line says RCCL."""
-    info = {"requested": args.backend, "fallback": False}
+    info = {"requested": args.backend, "fallback": False, "rccl_ranks": 0}
     if args.backend != "nccl":
         info["used"] = f"{args.backend} (candidates staged through the host)"
         return cpu_group, info
+    import datetime
     err, group = "", None
-    try:
-        import datetime
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=45))
-        x = torch.full((4,), float(rank), device=device)
-        out = torch.empty((4 * world,), device=device)
-        dist.all_gather_into_tensor(out, x, group=group)
-        torch.cuda.synchronize()
-        if not torch.equal(out.view(world, 4)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)):
-            err = "the probe all_gather returned wrong data"
-    except Exception as e:  # e.g. two ranks on one device: RCCL refuses ("Duplicate GPU detected")
-        err = repr(e)
+    # precondition, checked on the host-side group BEFORE any RCCL call: one device per rank.  RCCL
+    # refuses two ranks on a device ("Duplicate GPU detected"), and not necessarily on every rank
+    # at the same moment -- the others would sit in the probe collective until its timeout
+    ident = [None] * world
+    props = torch.cuda.get_device_properties(device)
+    dist.all_gather_object(ident, (socket.gethostname(), str(getattr(props, "uuid", device.index))),
+                           group=cpu_group)
+    if len(set(ident)) != world:
+        err = f"ranks share a device ({len(set(ident))} distinct devices for {world} ranks)"
+    else:
+        try:
+            # the probe runs on a group of its own with a SHORT timeout: a rank whose RCCL call
+            # raised reaches the flag reduction below at once, the others after 2 minutes at most
+            # (round-5 advisor finding: with the long timeout a one-sided failure was a 45-minute
+            # stall in front of the "loud fallback")
+            probe = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            x = torch.full((4,), float(rank), device=device)
+            out = torch.empty((4 * world,), device=device)
+            dist.all_gather_into_tensor(out, x, group=probe)
+            torch.cuda.synchronize()
+            if not torch.equal(out.view(world, 4)[:, 0].cpu(),
+                               torch.arange(world, dtype=torch.float32)):
+                err = "the probe all_gather returned wrong data"
+        except Exception as e:  # noqa: BLE001 -- reported in the line, every rank falls back
+            err = repr(e)
     flag = torch.tensor([1.0 if err else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=cpu_group)
+    if flag.item() == 0:
+        try:
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=45))
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        flag = torch.tensor([1.0 if err else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=cpu_group)
     if flag.item() > 0:
-        info.update(fallback=True, used="gloo (candidates staged through the host)",
+        info.update(fallback=True, used="gloo (candidates staged through the host)", rccl_ranks=0,
                     reason=(err or "the RCCL probe failed on another rank")[:500])
         if rank == 0:
             print("[bench] WARNING: the RCCL exchange was requested but its probe collective FAILED "
                   f"({info['reason']}); every rank falls back to the host-staged gloo exchange -- "
-                  "this line does NOT measure RCCL over xGMI", file=sys.stderr, flush=True)
+                  "this line does NOT measure RCCL over xGMI (rccl_ranks = 0)", file=sys.stderr,
+                  flush=True)
+        if args.require_rccl:
+            raise SystemExit(f"--require-rccl: no RCCL group of {world} ranks ({info['reason']})")
         return cpu_group, info
+    info["rccl_ranks"] = dist.get_world_size(group)
     info["used"] = "nccl = RCCL (one packed all_gather_into_tensor per batch, on the device)"
     return group, info
 
@@ -1090,7 +1128,8 @@ def run_in_process(args, ggnn):
         ids, dists = step()
     el, (ids, dists) = timed(step, args.steps, torch.cuda.synchronize)
     out = {"form": "one handle, set_gpus(%s), shard size %d" % (gpus, args.n_base),
-           "exchange": eng.last_exchange(), "queries_per_s": args.n_query / el,
+           "exchange": eng.last_exchange(), "rccl_ranks": eng.rccl_ranks(),
+           "queries_per_s": args.n_query / el,
            "blocking_half_batches_in_flight": eng.last_query_parts(),
            "ms_per_step": el * 1e3, "graph_build_wall_s": build_wall_s,
            "query_kernel_ms_max_over_gpus": eng.last_timing_ms()["query_ms"],
@@ -1233,6 +1272,8 @@ def run_sharded(args, device, ggnn, world, rank):
                                       f"shards, ONE packed RCCL all-gather of the sorted candidates "
                                       f"+ device k-way merge; value = Nq / T of blocking steps"},
             "exchange": exchange,
+            # ranks of the RCCL group the candidates travelled on: N, or 0 after a (loud) fallback
+            "rccl_ranks": exchange.get("rccl_ranks", 0),
             "recall_at_10": main["recall_at_10"],
             "graph_build_s_per_gpu": main["graph_build_s_per_gpu"],
             "graph_build_wall_s": main["graph_build_wall_s"],
@@ -1314,6 +1355,9 @@ def main():
                          "that a rocprofv3 --stats of the default command averages only "
                          "launches of the benchmark's own batch size)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: exit with an error instead of the (loud) gloo fallback when the RCCL "
+                         "group of N ranks cannot be created")
     ap.add_argument("--single-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ggnn_device_clock_hz": (_int, [_int, C.POINTER(C.c_double)]),
     "ggnn_last_build_work": (_int, [_vp, C.POINTER(BuildWork)]),
     "ggnn_last_query_parts": (_int, [_vp, C.POINTER(_u32)]),
+    "ggnn_rccl_ranks": (_int, [_vp, C.POINTER(_u32)]),
     "ggnn_set_hook": (_int, [C.c_char_p, C.c_int64]),
     "ggnn_reset_hook": (_int, [C.c_char_p]),
     "ggnn_get_hook": (_int, [C.c_char_p, C.POINTER(C.c_int64)]),

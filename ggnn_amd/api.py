@@ -426,6 +426,12 @@ class GGNN:
         self._check(lib().ggnn_last_query_parts(self._h, C.byref(n)))
         return int(n.value)
 
+    def rccl_ranks(self):
+        """ranks of the RCCL communicator behind the handle's exchange (0: none in use)"""
+        n = C.c_uint32()
+        self._check(lib().ggnn_rccl_ranks(self._h, C.byref(n)))
+        return int(n.value)
+
     def last_build_work(self):
         """work counters and kernel times of the merge / sym launches of the last build()
         (set_collect_counters(True) before the build): {"merge": {...}, "sym": {...}}"""

@@ -1406,8 +1406,8 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
   }
   if (use_i8v2) {
     m.gthr = hook(kHookBfI8NoShare) ? nullptr : gthr;  // (A/B hook)
-    // hook BF_I8_RANKS: bit mask of the published set positions the slices use (-1 = all; the
-    // highest bit of a set size alone = the single shared bound of rounds 3-4)
+    // hook BF_I8_RANKS: bit mask of the published set positions the slices use (31 = all five;
+    // the highest bit of a set size alone = the single shared bound of rounds 3-4; negative = auto)
     // default: ONE position -- an exchange costs ~0.2 ms per position and launch (measured: all
     // five 3.08 ms, the last entry alone 3.01, position 1 alone 2.28 for 10k x 1M x 128, k = 10) --
     // the lowest one that at most half of the slices have to reach (12 slices, sets of 10: position

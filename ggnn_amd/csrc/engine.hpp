@@ -214,6 +214,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart{nullptr};
   decltype(&ncclGroupEnd) GroupEnd{nullptr};
   decltype(&ncclGetErrorString) GetErrorString{nullptr};
+  decltype(&ncclCommCount) CommCount{nullptr};  // optional (tracing only)
   bool ok{false};
 
   static const Rccl& get()
@@ -235,6 +236,7 @@ struct Rccl {
       x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
       x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
       x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+      x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
       x.ok = x.CommInitAll && x.CommDestroy && x.AllGather && x.GroupStart && x.GroupEnd &&
              x.GetErrorString;
       return x;
@@ -595,6 +597,10 @@ struct ggnn_handle {
 
   void exchange_peer_copies(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
                             float* dists_out, bool blocking);
+  void merge_slices(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                    float* dists_out, bool blocking);
+  void exchange_gather_copies(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                              float* dists_out);
 
   void query_async(const void* d_query, uint64_t Nq, uint32_t D, ggnn_dtype dtype,
                    ggnn_location loc, int q_gpu, uint32_t k_query, float tau_query,

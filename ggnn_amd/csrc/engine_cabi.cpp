@@ -400,6 +400,20 @@ const char* ggnn_last_exchange(const ggnn_t* h)
   return h ? h->last_exchange : "none";
 }
 
+ggnn_status ggnn_rccl_ranks(const ggnn_t* h, uint32_t* ranks)
+{
+  GGNN_NEED_HANDLE(h);
+  uint32_t n = 0;
+  if (!h->comms.empty() && h->comms[0] && Rccl::get().ok && Rccl::get().CommCount) {
+    int count = 0;
+    if (Rccl::get().CommCount(h->comms[0], &count) == ncclSuccess && count > 0)
+      n = static_cast<uint32_t>(count);
+  }
+  if (ranks)
+    *ranks = n;
+  return GGNN_OK;
+}
+
 ggnn_status ggnn_last_bf_query_rescanned(const ggnn_t* h, uint32_t* n_rescanned)
 {
   GGNN_NEED_HANDLE(h);

@@ -16,13 +16,13 @@ void ggnn_handle::destroy_comms()
 // RCCL needs distinct devices per rank; a handle whose contexts share a device (tests on a
 // one-GPU box) and builds without librccl exchange through peer copies instead.
 // Hook EXCHANGE = 1 (rccl) | 2 (copy) forces one of the two (rccl also for a single GPU: a
-// 1-rank world).
+// 1-rank world); 3 (gather): exchange_gather_copies below.
 bool ggnn_handle::ensure_comms()
 {
   if (rccl_state != 0)
     return rccl_state > 0;
   rccl_state = -1;
-  if (hook(kHookExchange) == 2)
+  if (hook(kHookExchange) >= 2)
     return false;
   std::vector<int> ids;
   for (const DeviceCtx& ctx : devs)
@@ -79,6 +79,10 @@ void ggnn_handle::exchange(int lane, uint32_t nq, uint32_t k_query, size_t row, 
       rccl_state = -1;
       ++rccl_fallbacks;
     }
+  }
+  if (blocking && hook(kHookExchange) == 3) {
+    exchange_gather_copies(lane, nq, k_query, row, ids_out, dists_out);
+    return;
   }
   exchange_peer_copies(lane, nq, k_query, row, ids_out, dists_out, blocking);
 }
@@ -170,6 +174,17 @@ void ggnn_handle::exchange_rccl(int lane, uint32_t nq, uint32_t k_query, size_t 
   const ncclResult_t end = rccl.GroupEnd();
   GGNN_RCCL_CHECK(first_error);
   GGNN_RCCL_CHECK(end);
+  merge_slices(lane, nq, k_query, row, ids_out, dists_out, blocking);
+  last_exchange = "rccl";
+}
+
+// What follows the all-gather: GPU g merges its 1/G slice of the queries out of the gathered rows
+// (g_pack) and returns it; a blocking call then assembles the slices in the caller's arrays.
+void ggnn_handle::merge_slices(int lane, uint32_t nq, uint32_t k_query, size_t row, int32_t* ids_out,
+                  float* dists_out, bool blocking)
+{
+  const size_t G = devs.size();
+  const size_t part = nq * row;
   for (size_t g = 0; g < G; ++g) {
     DeviceCtx& ctx = devs[g];
     uint32_t first, count;
@@ -188,7 +203,39 @@ void ggnn_handle::exchange_rccl(int lane, uint32_t nq, uint32_t k_query, size_t 
   }
   if (blocking)
     finish_slices(lane, nq, k_query, G, ids_out, dists_out);
-  last_exchange = "rccl";
+}
+
+// Hook EXCHANGE = 3 ("gather"): the structure of the RCCL path WITHOUT RCCL -- every GPU gathers
+// the packed rows of all GPUs with peer copies (an all-gather spelled out), merges its 1/G slice
+// and returns it.  Exists so that the slice arithmetic, the G merge launches, the per-GPU staging
+// buffers and finish_slices of a handle with 8 contexts can run on a box whose contexts share one
+// device (RCCL refuses two ranks on a device); blocking calls only.
+void ggnn_handle::exchange_gather_copies(int lane, uint32_t nq, uint32_t k_query, size_t row,
+                            int32_t* ids_out, float* dists_out)
+{
+  const size_t G = devs.size();
+  const size_t part = nq * row;
+  for (DeviceCtx& ctx : devs) {
+    ctx.activate();
+    grow_lane(ctx, lane, ctx.xb[lane].g_pack, G * 2 * part * 4);
+    grow_lane(ctx, lane, ctx.xb[lane].m_pack, 2 * static_cast<size_t>(nq) * k_query * 4);
+    if (!ctx.xb[lane].done)
+      GGNN_HIP_CHECK(hipEventCreateWithFlags(&ctx.xb[lane].done, hipEventDisableTiming));
+    GGNN_HIP_CHECK(hipEventRecord(ctx.xb[lane].done, ctx.lane_stream(lane)));
+  }
+  for (size_t g = 0; g < G; ++g) {
+    DeviceCtx& ctx = devs[g];
+    ctx.activate();
+    hipStream_t st = ctx.lane_stream(lane);
+    for (size_t s = 0; s < G; ++s) {
+      if (s != g)
+        GGNN_HIP_CHECK(hipStreamWaitEvent(st, devs[s].xb[lane].done, 0));
+      GGNN_HIP_CHECK(hipMemcpyAsync(ctx.xb[lane].g_pack.as<int32_t>() + s * 2 * part,
+                                    devs[s].xb[lane].r_pack.p, 2 * part * 4, hipMemcpyDefault, st));
+    }
+  }
+  merge_slices(lane, nq, k_query, row, ids_out, dists_out, /*blocking=*/true);
+  last_exchange = "gather";
 }
 
 // Several contexts without RCCL (contexts sharing one device, or no librccl): packed rows to the

@@ -72,6 +72,8 @@ int64_t hook(Hook h)
           return 1;
         if (std::strcmp(e, "copy") == 0)
           return 2;
+        if (std::strcmp(e, "gather") == 0)
+          return 3;
       }
       return std::atoll(e);
     }

@@ -11,7 +11,7 @@ namespace ggnn_amd {
 
 enum Hook {
   kHookPrescreen = 0,   // PRESCREEN        default of new handles: 1 = exact pre-screen on
-  kHookExchange,        // EXCHANGE         0 auto | 1 "rccl" | 2 "copy"
+  kHookExchange,        // EXCHANGE         0 auto | 1 "rccl" | 2 "copy" | 3 "gather"
   kHookSymPrescreen,    // SYM_PRESCREEN    -1 auto (rows >= 1 KB) | 0 | 1
   kHookShardOverlap,    // SHARD_OVERLAP    1 = resident shards searched concurrently
   kHookVisSlots,        // VIS_SLOTS        usable keys per bucket of the hashed visited set (1..8)

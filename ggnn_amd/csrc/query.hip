@@ -457,13 +457,25 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
   args.vis_slots = vis_slots_hook();
   // long rings: per-query visited rings as stream-ordered scratch of this launch
   const uint32_t vis = args.cache - args.sorted;
+  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
+  // what launch_query_cfg / launch_query_r will pick for this shape, decided HERE so that the
+  // per-query scratch below is only allocated for kernels that use it (round-5 advisor finding:
+  // Nq x ring x 4 bytes -- 77 MB per 100k-query launch -- also went to layouts that keep the ring
+  // in LDS): the early-rows layouts (first row read 8 lanes x 16 bytes: Prescreen<8, 1> next to
+  // every float layout up to 128 dimensions, or rows of <= 128 bytes read directly) and the
+  // layouts that carry a hashed / tag set at all (pre-screened, or one chunk per lane)
+  const DistConfig dc = pick_dist_config(a.D, a.dtype);
+  const bool ps_kernel = use_ps && args.sorted <= 512;
+  const bool early_shape = ps_kernel ? !((dc.lpr == 16 && dc.nch == 4) || dc.lpr == 64)
+                                     : (dc.lpr == 8 && dc.nch == 1);
+  const bool set_shape = ps_kernel || dc.nch == 1;
   // ring-less hashed set (launch_query_r: early rows) when the search cannot wrap its ring: the
   // overflow lists of the launch (hook QUERY_GLOBAL_RING = 0: ring in LDS, A/B and test hook)
   const bool global_ring = args.sorted <= 64 && vis_hash_regs(vis) != 0 && a.max_iterations <= vis &&
                            a.KBuild <= 8 * kEarlySteps && hook(kHookQueryEarly) != 0 &&
-                           hook(kHookQueryGlobalRing) != 0;
-  if (global_ring ||
-      (args.sorted <= 64 && tag_set_usable(vis, a.N_base) && hook(kHookVisTagSet) != 0)) {
+                           hook(kHookQueryGlobalRing) != 0 && early_shape && set_shape;
+  if (global_ring || (args.sorted <= 64 && set_shape && tag_set_usable(vis, a.N_base) &&
+                      hook(kHookVisTagSet) != 0)) {
     args.tag_bits = global_ring ? 0 : tag_set_bucket_bits(vis);
     try {
       args.ring = static_cast<int32_t*>(
@@ -486,7 +498,6 @@ void launch_query(const QueryLaunch& a, hipStream_t stream)
         scratch_free(p, s);
     }
   } ring_guard{args.ring, stream};
-  const bool use_ps = a.ps_codes && a.ps_params && a.dtype == GGNN_F32;
   if (use_ps) {
     GGNN_REQUIRE(a.ps_Dc == prescreen_code_dim(a.D), GGNN_INVALID_ARGUMENT,
                  "pre-screen code rows must have prescreen_code_dim(D) bytes");

@@ -263,11 +263,46 @@ struct Dataset : public GenericDataset {
                       "hipMemcpyAsync");
     detail::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
   }
-  Dataset clone() const
+  // rows [from, from + num) -> the head of `other` (include/ggnn/base/dataset.cuh:156,
+  // dataset.cu:269-301: the reference's shard upload, gpu_instance.cu:491); enqueued on `stream`
+  // like the reference's cudaMemcpyAsync, host-to-host copies are immediate
+  void copyRangeTo(uint64_t from, uint64_t num, Dataset& other, hipStream_t stream = nullptr) const
   {
-    Dataset d = (isGPUAccessible() && !isCPUAccessible()) ? emptyOnGPU(N, D, gpu_id)
-                                                          : empty(N, D, false);
-    copyTo(d);
+    if (!mem_ || !other.mem_)
+      throw std::runtime_error("copyRangeTo: dataset without memory");
+    if (from > N || num > N - from)
+      throw std::out_of_range("copyRangeTo: rows [" + std::to_string(from) + ", " +
+                              std::to_string(from + num) + ") are out of bounds (N " +
+                              std::to_string(N) + ").");
+    const size_t bytes = static_cast<size_t>(num) * D * sizeof(T);
+    if (other.size_bytes() < bytes)
+      throw std::out_of_range("destination dataset is too small");
+    const T* src = data() + static_cast<size_t>(from) * D;
+    if (isCPUAccessible() && other.isCPUAccessible()) {
+      std::memcpy(other.mem_, src, bytes);
+      return;
+    }
+    // (GPUs of one process address each other's memory: no staging through the host as in
+    // dataset.cu:284-291)
+    detail::hip_check(hipMemcpyAsync(other.mem_, src, bytes, hipMemcpyDefault, stream),
+                      "hipMemcpyAsync");
+  }
+  Dataset clone(hipStream_t stream = nullptr) const
+  {
+    Dataset d = (isGPUAccessible() && !isCPUAccessible())
+                    ? emptyOnGPU(N, D, gpu_id)
+                    : empty(N, D, location == DataLocation::CPU_PINNED);
+    copyTo(d, stream);
+    return d;
+  }
+  // the data as seen from GPU gpu_id (include/ggnn/base/dataset.cuh:159, dataset.cu:326-334): a
+  // non-owning reference when it already lives there, else a copy in that GPU's memory
+  Dataset referenceOnGPU(int gpu_id_, hipStream_t stream = nullptr) const
+  {
+    if (isGPUAccessible() && gpu_id == gpu_id_)
+      return reference();
+    Dataset d = emptyOnGPU(N, D, gpu_id_);
+    copyTo(d, stream);
     return d;
   }
   Dataset reference() const { return Dataset(GenericDataset::reference()); }

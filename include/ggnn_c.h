@@ -155,9 +155,15 @@ ggnn_status ggnn_last_timing_ms(const ggnn_t* h, float* build_ms, float* query_m
 ggnn_status ggnn_last_query_counters(const ggnn_t* h, uint64_t* n_dist, uint64_t* n_pop);
 /* how the last ggnn_query combined the per-GPU results (replaces the D2H + CPU heap merge of
  * ggnn.cu:308-329 / result_merger.cpp:51-149): "none" (one GPU), "rccl" (grouped ncclAllGather
- * over xGMI + per-GPU slice merge) or "copy" (peer copies to the first GPU: contexts sharing one
- * device, or no librccl).  Hook EXCHANGE (ggnn_set_hook) forces one of them. */
+ * over xGMI + per-GPU slice merge) "copy" (peer copies to the first GPU: contexts sharing one
+ * device, or no librccl) or "gather" (hook EXCHANGE = 3).  Hook EXCHANGE (ggnn_set_hook) forces
+ * one of them. */
 const char* ggnn_last_exchange(const ggnn_t* h);
+/* ranks of the RCCL communicator the handle's exchange runs on (ncclCommCount of its first
+ * communicator): the number of GPUs of the handle once an "rccl" exchange has run, 0 before that,
+ * without librccl, or after a fallback to peer copies.  A multi-GPU benchmark line that says
+ * "rccl" must carry this number equal to its GPU count. */
+ggnn_status ggnn_rccl_ranks(const ggnn_t* h, uint32_t* ranks);
 /* number of half-batches the last blocking multi-GPU ggnn_query was searched in: 2 when the search
  * of the second half overlapped the exchange and merge of the first (hook QUERY_SPLIT), else 1 */
 ggnn_status ggnn_last_query_parts(const ggnn_t* h, uint32_t* parts);
@@ -221,7 +227,10 @@ void ggnn_set_log_level(int level);
  *   name             default  values
  *   PRESCREEN           1     default of ggnn_set_prescreen for handles created afterwards
  *   EXCHANGE            0     0 auto | 1 ("rccl") RCCL all-gather, also on one GPU (1-rank world)
- *                             | 2 ("copy") peer copies to the first GPU
+ *                             | 2 ("copy") peer copies to the first GPU | 3 ("gather", blocking
+ *                             calls) every GPU gathers all rows by peer copies and merges its
+ *                             1/G slice: the RCCL path's structure without RCCL, for handles whose
+ *                             contexts share a device
  *   SYM_PRESCREEN      -1     sym kernel with the pre-screen: -1 auto (rows >= 1 KB) | 0 | 1
  *   SHARD_OVERLAP       1     0 = resident shards of one GPU searched one launch at a time
  *   VIS_SLOTS           8     usable keys per bucket of the hashed visited set, 1..8 (small values

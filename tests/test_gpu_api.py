@@ -374,6 +374,53 @@ def test_in_process_multi_gpu(orc, shard_size):
         eng.query(q, K, 0.7)
 
 
+@pytest.mark.parametrize("nq", [37, 5, 64])
+def test_eight_contexts_gather_and_slice_merges(orc, nq):
+    """What an 8-GPU handle does behind its all-gather, on the one-GPU box: set_gpus([0] * 8) with
+    two shards per context, hook EXCHANGE = 3 ("gather": every context gathers all rows by peer
+    copies, merges ITS 1/8 slice of the queries and returns it through its own staging buffer --
+    the RCCL path's structure without RCCL, which refuses two ranks on one device).  Query counts
+    that 8 does not divide (37: slices of 5,5,5,5,5,5,5,2) and fewer queries than contexts (5:
+    three empty slices), unsplit and as two half-batches in flight -- against the reference's
+    per-GPU sort + ResultMerger (gpu_instance.cu:745-790, result_merger.cpp:51-149)."""
+    import ggnn_amd as ggnn
+    from ggnn_amd import _lib
+    N, D, K, NSH = 8000, 32, 10, 500
+    base, q = make_int_data(N, D, 187), make_int_data(nq, D, 188)
+    eng = ggnn.GGNN()
+    eng.set_base(base)
+    eng.set_gpus([0] * 8)
+    eng.set_shard_size(NSH)
+    eng.build(24, 0.5, 1)
+    spg = N // NSH // 8
+    parts_i, parts_d = [], []
+    for gpu in range(8):
+        rows_i, rows_d = [], []
+        for s in range(spg):
+            gs = gpu * spg + s
+            g = eng.get_graph(gs)
+            lo = gs * NSH
+            o = orc.query(base[lo:lo + NSH], q, g.graph[0].view.numpy(),
+                          g.translation[3].view.numpy().reshape(-1),
+                          g.nn1_stats.view.numpy().reshape(-1), K, 0.7, 200)
+            rows_i.append(o[0] + s * NSH)
+            rows_d.append(o[1])
+        si, sd = orc.sort_shard_results(np.concatenate(rows_i, 1), np.concatenate(rows_d, 1))
+        parts_i.append(si)
+        parts_d.append(sd)
+    r_ids, r_d = orc.merge_results(parts_i, parts_d, K, spg, NSH)
+    uniq = np.ones_like(r_d, bool)
+    uniq[:, 1:] &= r_d[:, 1:] != r_d[:, :-1]
+    uniq[:, :-1] &= r_d[:, :-1] != r_d[:, 1:]
+    for exchange, split in ((3, 0), (3, 1), (2, 0)):
+        with _lib.hooks(EXCHANGE=exchange, QUERY_SPLIT=split):
+            ids, d = eng.query(q, K, 0.7, 200)
+        assert eng.last_exchange() == ("gather" if exchange == 3 else "copy")
+        assert eng.last_query_parts() == (2 if split else 1)
+        assert np.array_equal(d.numpy(), r_d), (exchange, split)
+        assert np.array_equal(ids.numpy()[uniq], r_ids[uniq]), (exchange, split)
+
+
 def test_uint8_and_cosine_through_the_api(orc):
     """uint8 base (SIFT-like) and cosine measure through the public surface incl. the Evaluator"""
     import ggnn_amd as ggnn

@@ -71,12 +71,18 @@ def test_bench_two_ranks_rccl_is_attempted_and_falls_back_loudly():
     out = json.loads(lines[0])
     ex = out["exchange"]
     assert ex["requested"] == "nccl"
-    if ex["fallback"]:      # one GPU: RCCL refuses two ranks on a device
-        assert ex["used"].startswith("gloo") and ex["reason"]
+    if ex["fallback"]:      # one GPU: both ranks share device 0 -- found by the precondition check
+        assert ex["used"].startswith("gloo") and ex["reason"]   # (no RCCL call, no timeout to sit out)
         assert "WARNING" in r.stderr and "does NOT measure RCCL" in r.stderr
+        assert out["rccl_ranks"] == 0 and "share a device" in ex["reason"]
     else:                   # (a box where the probe works: then the line must say RCCL)
-        assert "RCCL" in ex["used"]
+        assert "RCCL" in ex["used"] and out["rccl_ranks"] == 2
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["recall_at_10"] > 0.9
+    # --require-rccl turns the loud fallback into a failure of the command
+    r2 = subprocess.run(cmd + ["--require-rccl"], cwd=ROOT, env=env, capture_output=True, text=True,
+                        timeout=600)
+    if ex["fallback"]:
+        assert r2.returncode != 0 and "--require-rccl" in (r2.stderr + r2.stdout)
 
 
 def test_bench_lean_line_contract():
@@ -101,3 +107,38 @@ def test_bench_u8_and_cosine_flags():
     out = run([sys.executable, "bench.py", "--lean", "--steps", "2", "--warmup", "1",
                "--n-base", "30000", "--n-query", "500", "--dim", "256", "--measure", "cosine"])
     assert "cosine" in out["config"]["workload"] and out["recall_at_10"] > 0.5
+
+
+def test_sift1m_real_plumbing_on_synthetic_files(tmp_path):
+    """bench.sift1m_real (the real-dataset leg behind $GGNN_SIFT1M_DIR: the reference's four
+    published SIFT1M settings, examples/python/sift1m_fvecs.py:19-30) on synthetic files with the
+    TEXMEX names and formats -- sift_base.fvecs, sift_query.fvecs, sift_groundtruth.ivecs (100
+    neighbours per query) -- so that the first box that has the real files cannot fail on
+    plumbing: loaders, shapes, ground truth of the file against the engine's exact brute force."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    import ggnn_amd as ggnn
+    dev = torch.device("cuda", 0)
+    base = bench.synthetic("lowrank16", 30_000, 128, 1234, dev)
+    query = bench.synthetic("lowrank16", 500, 128, 4321, dev)
+    eng = ggnn.GGNN()
+    eng.set_base_reference(base)
+    eng.set_return_results_on_gpu(True)
+    gt100, _ = eng.bf_query(query, 100)
+    ggnn.FloatDataset(base.cpu()).store(str(tmp_path / "sift_base.fvecs"))
+    ggnn.FloatDataset(query.cpu()).store(str(tmp_path / "sift_query.fvecs"))
+    ggnn.IntDataset(gt100.cpu()).store(str(tmp_path / "sift_groundtruth.ivecs"))
+    del eng
+    # the files have the TEXMEX record layout: int32 D, then D values
+    raw = np.fromfile(tmp_path / "sift_groundtruth.ivecs", dtype=np.int32).reshape(500, 101)
+    assert (raw[:, 0] == 100).all()
+    out = bench.sift1m_real(str(tmp_path), ggnn, dev)
+    assert out["N"] == 30_000 and out["Nq"] == 500 and out["graph_build_s"] > 0
+    assert out["groundtruth_file"]["bf_query_agrees_at_10"] == 1.0
+    assert len(out["points"]) == 4
+    for name, p in out["points"].items():
+        assert p["queries_per_s"] > 0 and 0.5 < p["c_at_10"] <= 1.0, name
+        assert p["c_at_10_vs_groundtruth_file"] == p["c_at_10"], name
+    assert out["points"]["tau=0.64,iters=400"]["c_at_10"] > 0.98

@@ -280,9 +280,12 @@ def test_uint8_register_list_kernel_exact(orc, monkeypatch, N, D, Nq, K):
     q[5:205] = base[100:300]                        # exact hits with three copies each
     o_ids, o_d = orc.bf_query(base, q, K)
     d_base, d_q = torch.from_numpy(base).cuda(), torch.from_numpy(q).cuda()
-    # slices: the bound exchange between them (bf_i8.hip) with every position, single positions
-    # (16 = the last entry alone: rounds 3-4), too few slices for most positions, 32 slices, none
-    for env in ({}, {"GGNN_BF_SLICES": "7"}, {"GGNN_BF_SLICES": "23", "GGNN_BF_I8_RANKS": "16"},
+    # slices: the bound exchange between them (bf_i8.hip) with the default (BF_I8_RANKS = -1: ONE
+    # position chosen from the slice count), ALL five positions together (31: the exchange with
+    # m = 10, 5, 4, 2, 1 at once), single positions (16 = the last entry alone: rounds 3-4), too few
+    # slices for most positions, 32 slices, none
+    for env in ({}, {"GGNN_BF_SLICES": "7"}, {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_RANKS": "31"},
+                {"GGNN_BF_SLICES": "7", "GGNN_BF_I8_RANKS": "31"}, {"GGNN_BF_SLICES": "23", "GGNN_BF_I8_RANKS": "16"},
                 {"GGNN_BF_SLICES": "1"}, {"GGNN_BF_I8_V1": "1"}, {"GGNN_BF_SLICES": "2"},
                 {"GGNN_BF_SLICES": "5", "GGNN_BF_I8_RANKS": "3"}, {"GGNN_BF_SLICES": "32"},
                 {"GGNN_BF_SLICES": "12", "GGNN_BF_I8_RANKS": "2"},

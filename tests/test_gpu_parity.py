@@ -175,14 +175,16 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the 192-entry ring"
     if iters in (500, 512):
         assert int(o_np.max()) > 480 + 16, "the case is meant to wrap the 480-entry ring"
-    # 257..480 iterations that cannot wrap their ring (480 / 448 keys): the early-rows kernel keeps
-    # the ring in GLOBAL memory (SortedList<1, 2, true>); 1-2 usable slots overflow the stash there,
-    # i.e. the membership test scans the global ring for the rest of the search
+    # 257..480 iterations that cannot wrap their ring (480 / 448 keys): the early-rows kernel has NO
+    # ring (SortedList<1, 2, true>: buckets + stash are the visited keys); with 1-2 usable slots
+    # the stash overflows and later keys go to the overflow list in global memory, which every
+    # membership test then scans
     if iters in (480, 448):
         assert int(o_np.max()) > 400, "the case is meant to fill most of its ring"
     # 1000..2048 iterations: rings of 992 / 2016 keys kept in global memory and mirrored in the
-    # 16-bit tag set (traversal.hpp kTagSet): 1-2 usable slots overflow the stash (the scan of the
-    # global ring takes over), 4 fill it; 1000 / 1024 iterations on a 992-key ring wrap it
+    # 16-bit tag set (traversal.hpp "long rings": 7 tags + their number per 16-byte bucket): 1-2
+    # usable slots overflow the stash (the scan of the global ring takes over), 4 fill it; 1000 /
+    # 1024 iterations on a 992-key ring wrap it
     if (tau, iters) == (4.0, 1000):
         assert int(o_np.max()) > 900, "the case is meant to fill the 992-entry ring"
     if (tau, iters) == (5.0, 2048):
@@ -680,6 +682,21 @@ def test_bf_mfma_int_exact(ops, orc, dtype, N, D, Nq, K):
     o_ids, o_d = orc.bf_query(base, q, K)
     assert np.array_equal(ids.cpu().numpy(), o_ids)
     assert np.array_equal(d.cpu().numpy(), o_d)
+
+
+def test_bf_query_baseline_config0_shape(ops, orc):
+    """BASELINE configs[0] at its exact shape: 10 000 x 128 float32 base, 10 000 queries, k = 10
+    (S-int of SURVEY 8(d): seeds 1234 / 4321).  The whole batch runs on the GPU; 256 evenly spaced
+    queries are compared with the oracle (the CPU restatement needs seconds for these, minutes for
+    all), and every returned row is checked to be sorted."""
+    base, q = make_int_data(10_000, 128, 1234), make_int_data(10_000, 128, 4321)
+    ids, d = ops.bf_query(dev(base), dev(q), 10)
+    ids, d = ids.cpu().numpy(), d.cpu().numpy()
+    assert ids.shape == (10_000, 10) and (np.diff(d, axis=1) >= 0).all()
+    pick = np.arange(0, 10_000, 39)[:256]
+    o_ids, o_d = orc.bf_query(base, q[pick], 10)
+    assert np.array_equal(ids[pick], o_ids)
+    assert np.array_equal(d[pick], o_d)
 
 
 def test_bf_mfma_ties_and_duplicates(ops, orc):
