@@ -141,4 +141,4 @@ def test_sift1m_real_plumbing_on_synthetic_files(tmp_path):
     for name, p in out["points"].items():
         assert p["queries_per_s"] > 0 and 0.5 < p["c_at_10"] <= 1.0, name
         assert p["c_at_10_vs_groundtruth_file"] == p["c_at_10"], name
-    assert out["points"]["tau=0.64,iters=400"]["c_at_10"] > 0.98
+    assert out["points"]["tau=0.64,iters=400"]["c_at_10"] > 0.95      # (plumbing, not a recall claim)
