@@ -20,6 +20,7 @@ constexpr Entry kTable[kHookCount] = {
     {"BF_I8_NOSHARE", 0}, {"BF_I8_RANKS", -1},    {"BF_SCAN", 0},        {"RCCL_FAIL_AFTER", 0},
     {"QUERY_EARLY", 1},   {"MERGE_EARLY", 1},   {"QUERY_LDS_PAD", 0},
     {"QUERY_GLOBAL_RING", 1}, {"BF_I8_REFRESH", 64}, {"BF_I8_SEED", 0},
+    {"MERGE_COUNTING", 0},
 };
 std::atomic<bool> g_set[kHookCount];
 std::atomic<int64_t> g_value[kHookCount];

@@ -37,6 +37,7 @@ enum Hook {
   kHookQueryGlobalRing, // QUERY_GLOBAL_RING 0 = early-rows kernels keep a visited ring in LDS even when it cannot wrap
   kHookBfI8Refresh,     // BF_I8_REFRESH    stages between bound exchanges of the i8 kernel's slices
   kHookBfI8Seed,        // BF_I8_SEED       rows of the i8 kernel's seeding launch (0 = none)
+  kHookMergeCounting,   // MERGE_COUNTING   1 = merge launches without counters use the counting kernel too
   kHookCount
 };
 

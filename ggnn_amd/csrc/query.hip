@@ -32,6 +32,11 @@ GGNN_DEV void load_prescreen(PSC& ps, const QueryArgs& a, const BaseT* qrow)
 // EARLY (R = 1, KBuild <= 24; traversal.hpp "Early rows"): the first-read rows of a pop's neighbours
 // are requested before the pop's bookkeeping and the membership test instead of after them.
 // GR (with EARLY and a hashed set): the visited ring in global memory (SortedList<R, HB, true>).
+// (fetch_early<.., COUNT = false> -- the sorted part of the cache tested behind the verdicts, for the
+// candidates still in the race -- is used by the merge kernel only: measured here on one box,
+// round 6, it is 3 % SLOWER on 10 000-query batches (1.186 -> 1.225 ms headline, 7.36 -> 7.57 ms
+// lowrank24 at 1.0 / 750: the per-candidate compare chain sits between the verdicts and the float
+// rows of a wave that is bound by its own latency) and even on 100 000-query batches.)
 template <typename BaseT, int LPR, int NCH, int R, int MODE, class PSC, int HB = 0, bool EARLY = false,
           bool GR = false>
 __global__ void __launch_bounds__(kWave) __attribute__((

@@ -700,6 +700,30 @@ struct SortedList {
     head_in = (head_in + 1 >= P) ? 0 : head_in + 1;
   }
 
+  // Second half of the membership test of simple_knn_cache.cuh:246-261 for kernels that skipped
+  // the scan of the sorted part (filter<.., false>): clears the bits of `m` whose candidate (lane
+  // j holds its key in k_of) sits in the best list or the priority queue.  Must run before the
+  // first push of the fetch -- the reference tests every candidate against the cache as it is when
+  // the fetch starts -- and costs one compare per candidate that is still in the race (the ~5
+  // that passed the pre-screen, or the ~4 whose distance beats the criteria) instead of a scan
+  // of 32 / 64 keys for all 24.
+  GGNN_DEV unsigned long long drop_sorted(unsigned long long m, const int k_of) const
+  {
+    unsigned long long out = m;
+    while (m) {
+      const int j = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const int k = rdlane(k_of, j);
+      bool hit = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        hit |= (key[r] == k);
+      if (__any(hit))
+        out &= ~(1ull << j);
+    }
+    return out;
+  }
+
   // simple_knn_cache.cuh:297-333 ; goes through LDS (known[0,SORTED)), called once per layer
   GGNN_DEV void transform(const int32_t* selection, int* known, float* scratch_d)
   {
@@ -763,20 +787,28 @@ struct SortedList {
   // AHEAD: the reads of the next pair of 16-byte groups are issued before the current pair is
   // folded (a lone wave otherwise pays one LDS latency per pair).  The early-rows order runs the
   // test under the latency of the candidates' row loads and prefers the 8 registers.
-  template <bool AHEAD = true>
+  // SCAN_SORTED = false (kernels that do not count evaluations, fetch_early<.., COUNT = false>):
+  // only the VISITED keys are tested here -- the hashed / tag set, stash and overflow list -- and
+  // the sorted part is tested later, for the few candidates that would go on to the float rows
+  // (drop_sorted below).  Only while the set is in use: once a search has fallen back to the ring
+  // scan (scan_mode) the full test runs as before.
+  template <bool AHEAD = true, bool SCAN_SORTED = true>
   GGNN_DEV int filter(int cand, int* known) const
   {
     const int lane = threadIdx.x;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = r * kWave + lane;
-      if (i < SORTED)
-        known[i] = key[r];
-    }
-    __syncthreads();
     // with the hashed set only the sorted part is scanned; the visited ring is one bucket read
     const bool hashed = (HB != 0) && !scan_mode;
+    const bool scan = SCAN_SORTED || !hashed;
+    if (scan) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = r * kWave + lane;
+        if (i < SORTED)
+          known[i] = key[r];
+      }
+      __syncthreads();
+    }
     const int E = (hashed || kGlobalRing || GR) ? SORTED : SORTED + vis_count;
     const int h = lane >> 5;
     const int4* kp = reinterpret_cast<const int4*>(known);
@@ -838,9 +870,12 @@ struct SortedList {
     }
     const int4* p = kp + h;
     const int T = (E + 7) >> 3;  // >= 4: SORTED >= 32
+    if (!scan) {
+      // (visited keys only: nothing of known[] is read)
+    }
     // the reads of the next pair are issued before the current pair is folded: a lone wave
     // (small batches, tail of a launch) otherwise pays one LDS latency per pair
-    if constexpr (AHEAD) {
+    else if constexpr (AHEAD) {
       int4 e0 = p[0], e1 = p[2];
       int t = 0;
       for (; t + 4 <= T; t += 2) {
@@ -1686,14 +1721,18 @@ GGNN_DEV void replay_lanes(SL& sl, unsigned long long m, const int k_of, const f
 
 // second half of a pop in the early-rows order: membership test, verdicts, exact phase, replay.
 // cand: lane j (< 24) holds candidate j or EMPTY (the value issue() was given).
-template <int MODE, class SL, class DE, class PS, class ER, class HOOK>
+// COUNT = false (launches that do not collect work counters: every production call): the scan of
+// the sorted part moves behind the verdicts (SortedList::drop_sorted) -- same candidates on the
+// float rows, same pushes, same results; the return value and `rows` then count the survivors of
+// the VISITED test only and are not used.
+template <int MODE, bool COUNT = true, class SL, class DE, class PS, class ER, class HOOK>
 GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, const ER& er,
                          const PS& ps, uint2& rows, HOOK&& after_filter,
                          const int32_t* translation = nullptr)
 {
   const int lane = threadIdx.x;
   const int grp = lane >> 3, w = lane & 7;
-  cand = sl.template filter<false>(lower_half_to_both(cand), lds.known);
+  cand = sl.template filter<false, COUNT>(lower_half_to_both(cand), lds.known);
   const unsigned surv = static_cast<unsigned>(__ballot(lane < 32 && cand != kEmptyKey));
   const int nsurv = __popc(surv);
   after_filter();
@@ -1714,13 +1753,17 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
 #pragma unroll
     for (int s = 0; s < kEarlySteps; ++s)
       S[s] = group_sum<8>(ps.partial(er.v[s]));  // (every lane of the group holds the sum)
-    const bool pass = alive && !(ER::of_my_step(S[0], S[1], S[2]) >= s_thr);
-    const unsigned long long pm = __ballot(pass);   // ascending lanes = ascending candidates
+    bool pass = alive && !(ER::of_my_step(S[0], S[1], S[2]) >= s_thr);
+    unsigned long long pm = __ballot(pass);   // ascending lanes = ascending candidates
+    const int mykey = ER::of_my_step(er.kk[0], er.kk[1], er.kk[2]);
+    if constexpr (!COUNT) {
+      pm = sl.drop_sorted(pm, mykey);
+      pass = (pm >> lane) & 1ull;
+    }
     const int neval = __popcll(pm);
     if (neval == 0)
       return nsurv;
     rows.x += neval;
-    const int mykey = ER::of_my_step(er.kk[0], er.kk[1], er.kk[2]);
     constexpr int kSteps = StepsOf<DE::LPR, DE::NCH>::value;
     constexpr int kExactSteps = (DE::NCH == 3 && DE::ROWS >= 8) ? 1 : (kSteps > 2) ? 2 : kSteps;
     // keys of the candidates that pass -> LDS in candidate order (one write: the ballot is already
@@ -1755,7 +1798,11 @@ GGNN_DEV int fetch_early(SL& sl, const DE& de, const WaveLds& lds, int cand, con
       dd[s] = (MODE == kCos) ? de.finish_cos(a, b) : a;
     }
     const float dmine = ER::of_my_step(dd[0], dd[1], dd[2]);
-    replay_lanes(sl, __ballot(alive && dmine < sl.criteria()), ER::of_my_step(er.kk[0], er.kk[1], er.kk[2]), dmine);
+    const int mykey = ER::of_my_step(er.kk[0], er.kk[1], er.kk[2]);
+    unsigned long long m = __ballot(alive && dmine < sl.criteria());
+    if constexpr (!COUNT)
+      m = sl.drop_sorted(m, mykey);
+    replay_lanes(sl, m, mykey, dmine);
     return nsurv;
   }
 }

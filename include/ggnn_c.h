@@ -273,7 +273,12 @@ void ggnn_set_log_level(int level);
  *   QUERY_GLOBAL_RING   1     early-rows query kernels whose search cannot wrap its visited ring
  *                             (max_iterations <= ring length): 1 = no ring at all, the hashed set's
  *                             buckets and stash ARE the visited keys (overflow list in global
- *                             memory); 0 = ring in LDS mirrored by the set */
+ *                             memory); 0 = ring in LDS mirrored by the set
+ *   MERGE_COUNTING      0     merge launches WITHOUT work counters (every production build) run a
+ *                             kernel that tests a candidate against the sorted part of the cache
+ *                             only once it has passed the pre-screen; 1 = they run the counting
+ *                             kernel, which scans the sorted part for every candidate first (same
+ *                             graph; A/B and test hook) */
 ggnn_status ggnn_set_hook(const char* name, int64_t value);
 /* back to environment / default */
 ggnn_status ggnn_reset_hook(const char* name);

@@ -240,7 +240,7 @@ def test_hooks_api(lib, monkeypatch):
     header = open(os.path.join(ROOT, "include", "ggnn_c.h")).read()
     names = ["PRESCREEN", "EXCHANGE", "SYM_PRESCREEN", "SHARD_OVERLAP", "VIS_SLOTS", "VIS_TAG_SET", "QUERY_SPLIT", "RESIDENT_SHARDS", "XCD_MAP",
              "BF_POOL_KEEP_MB", "BF_NO_I8", "BF_I8_V1", "BF_SLICES", "BF_NO_CENTER", "BF_TILES",
-             "BF_I8_NOSHARE", "BF_I8_RANKS", "BF_SCAN", "RCCL_FAIL_AFTER", "QUERY_EARLY", "MERGE_EARLY", "QUERY_LDS_PAD", "QUERY_GLOBAL_RING", "BF_I8_REFRESH", "BF_I8_SEED"]
+             "BF_I8_NOSHARE", "BF_I8_RANKS", "BF_SCAN", "RCCL_FAIL_AFTER", "QUERY_EARLY", "MERGE_EARLY", "QUERY_LDS_PAD", "QUERY_GLOBAL_RING", "BF_I8_REFRESH", "BF_I8_SEED", "MERGE_COUNTING"]
     for n in names:
         assert re.search(r"\*\s+" + n + r"\s", header), f"hook {n} is not documented in ggnn_c.h"
         _lib.get_hook(n)

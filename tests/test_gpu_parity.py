@@ -165,12 +165,17 @@ def test_query_visited_hash_paths_exact(ops, orc, small_graph, slots, K, tau, it
     # the pre-screened float kernel is the one that carries the hash set (the plain two-chunk
     # float kernel keeps the ring scan, see launch_query_r)
     b = dev(g["base"])
+    ps = ops.prescreen_encode(b)
     ids, d, nd, npop = ops.query(b, dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]), K,
-                                 tau, iters, counters=True, prescreen=ops.prescreen_encode(b))
+                                 tau, iters, counters=True, prescreen=ps)
     assert np.array_equal(ids.cpu().numpy(), o_ids)
     assert np.array_equal(d.cpu().numpy(), o_d)
     assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np)
     assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+    # (and the kernels of launches without counters: stash / overflow list / ring scan as above)
+    ids, d = ops.query(b, dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]), K, tau, iters,
+                       prescreen=ps)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
     if iters in (250, 255):
         assert int(o_np.max()) > 192 + 16, "the case is meant to wrap the 192-entry ring"
     if iters in (500, 512):
@@ -220,6 +225,13 @@ def test_query_orders_and_ring_homes_equal_the_oracle(ops, orc, small_graph, dty
         assert np.array_equal(d.cpu().numpy(), o_d), (early, gring)
         assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), (early, gring)
         assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), (early, gring)
+        # the same launch WITHOUT counters: the ring-less kernels then test the sorted part of the
+        # cache behind the verdicts, for the candidates still in the race (fetch_early<.., false>)
+        with _lib.hooks(QUERY_EARLY=early, QUERY_GLOBAL_RING=gring):
+            ids, d = ops.query(b, dev(q), dev(graph0), dev(start_points(g)), dev(g["stats"]), K, tau,
+                               iters, prescreen=ps)
+        assert np.array_equal(ids.cpu().numpy(), o_ids), (early, gring, "no counters")
+        assert np.array_equal(d.cpu().numpy(), o_d), (early, gring, "no counters")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
@@ -257,6 +269,10 @@ def test_query_early_rows_on_arbitrary_graph_rows(ops, orc, dtype, KB):
         assert np.array_equal(d.cpu().numpy(), o_d), early
         assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd), early
         assert np.array_equal(npop.cpu().numpy().astype(np.uint32), o_np), early
+    # without counters (sorted part tested behind the verdicts): duplicates in a row, self loops and
+    # EMPTY slots must give the same lists
+    ids, d = ops.query(b, dev(q), dev(graph), dev(start), dev(stats), 10, 1.2, 150, prescreen=ps)
+    assert np.array_equal(ids.cpu().numpy(), o_ids) and np.array_equal(d.cpu().numpy(), o_d)
     assert int(o_np.max()) > 20
 
 
@@ -318,6 +334,9 @@ def test_merge_visited_hash_paths_exact(ops, orc, small_graph, slots, top, btm, 
                             0.5, top, btm, counters=True, prescreen=ops.prescreen_encode(b))
     assert np.array_equal(gb.cpu().numpy(), o_gb)
     assert np.array_equal(nd.cpu().numpy().astype(np.uint32), o_nd)
+    gb2, _ = ops.merge(b, c, dev(g["graph"]), dev(g["tr"]), dev(g["sel"]), dev(g["stats"]), 0.5, top,
+                       btm, prescreen=ops.prescreen_encode(b))     # (the non-counting kernel)
+    assert np.array_equal(gb2.cpu().numpy(), o_gb)
 
 
 def test_query_shard_offsets(ops, orc, small_graph):
