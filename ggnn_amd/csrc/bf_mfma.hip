@@ -572,7 +572,9 @@ GGNN_DEV float bf_expand(float dot, float qn, float bn, bool jvalid)
 // NU (T = 1 only): float4 steps per half row, Dh = 4*NU -- a compile-time trip count keeps the
 // MFMA chain of a tile in ONE basic block so that the LDS reads of the B operand are scheduled
 // ahead of the MFMAs that consume them.
-template <typename BaseT, int MODE, int T, int NU>
+// KPC: the list length KP as a compile-time constant (0: a.KP at run time) -- every list address
+// of the epilogue and of the insertions is then a constant offset from one base.
+template <typename BaseT, int MODE, int T, int NU, int KPC = 0>
 __global__ void __launch_bounds__(256)
     __attribute__((amdgpu_waves_per_eu(T == 1 ? 3 : T <= 3 ? 2 : 1))) bf_mfma_kernel(const BfMfmaArgs a)
 {
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(256)
   const int j = lane & 31, h = lane >> 5;
   const BaseT* base = static_cast<const BaseT*>(a.base);
   const BaseT* query = static_cast<const BaseT*>(a.query);
-  const uint32_t KP = a.KP;
+  const uint32_t KP = KPC ? static_cast<uint32_t>(KPC) : a.KP;
   const uint32_t nch = (a.D + CW - 1) / CW;
   float aq[64];
   // rows of the accumulator registers: i(r) = (r&3) + 8*(r>>2) + 4*h
@@ -1383,6 +1385,10 @@ void launch_bf_query_mfma(const BfLaunch& a, hipStream_t stream)
                            : tiles_per_group == 3                                                 \
                            ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 3, 16>)      \
                            : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 4, 16>))     \
+                       : (KP == 18) /* k = 10: the list length as a constant (see the kernel) */   \
+                           ? ((Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8, 18>)  \
+                              : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12, 18>) \
+                                           : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 16, 18>))\
                        : (Dh == 32) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 8>)  \
                        : (Dh == 48) ? reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 12>) \
                                     : reinterpret_cast<const void*>(&bf_mfma_kernel<T, MODE_, 1, 16>);\
